@@ -1,0 +1,134 @@
+/*
+ * xdfm.h -- C ABI of libxdfm_hip.so: the MI355X (gfx950) hot path of xDeepFM.
+ *
+ * The reference (Syclus123/xDeepFM-pytorch) has no FFI: its boundary for this path is a
+ * Python class API made of stock ATen calls.  Every entry point below replaces one group of
+ * those calls; the citation after "replaces:" is the reference file:line (relative to the
+ * reference root) whose arithmetic the kernel reproduces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked [host]; buffers are caller-allocated;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and never
+ *     synchronise, allocate or free (safe under hipGraph capture);
+ *   - return value: 0 = ok, otherwise an XDFM_ERR_* code; xdfm_last_error() gives the text;
+ *   - "FM layout" (feature-map major) of an activation with R rows for a batch of B examples
+ *     and embedding width D:  T[r][n], n = b*D + d, row pitch N = B*D floats.  It is the
+ *     reference's [B, R, D] tensor with the R axis outermost, so that the 64 lanes of a
+ *     wavefront read consecutive n and one example's D values are contiguous.
+ *   - all arithmetic is IEEE fp32 ("dtype f32"); contractions run on v_mfma_f32_32x32x2_f32.
+ */
+#ifndef XDFM_H
+#define XDFM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XDFM_ABI_VERSION 1
+
+enum {
+    XDFM_OK = 0,
+    XDFM_ERR_INVALID = 1,   /* bad shape / null pointer / unsupported option */
+    XDFM_ERR_LAUNCH = 2,    /* HIP reported an error at launch */
+    XDFM_ERR_NO_DEVICE = 3
+};
+
+enum { XDFM_ACT_LINEAR = 0, XDFM_ACT_RELU = 1 };
+
+int xdfm_abi_version(void);
+const char* xdfm_last_error(void);          /* [host] thread-local, never NULL */
+int xdfm_device_count(void);                /* <0: HIP error code negated */
+/* tuning knobs for A/B runs (e.g. "fwd_nf", "bww_nsplit"); unknown key -> XDFM_ERR_INVALID */
+int xdfm_set_option(const char* key, int value);
+int xdfm_get_option(const char* key);
+
+/* ------------------------------------------------------------------ embedding gather (K1)
+ * replaces: deepctr/models/basemodel.py:368-370 (26x slice -> .long() -> nn.Embedding),
+ *           deepctr/models/basemodel.py:63-92 (Linear: 1-dim tables, sum, dense @ weight),
+ *           deepctr/models/xdeepfm.py:86 + deepctr/inputs.py:126-132 (the two concatenations).
+ * X        [B][ldx] fp32; ids travel as fp32 exactly as basemodel.py:242 makes them.
+ * tables   device array of m table base pointers, table j is [vocab[j]][D];
+ * lin_tables device array of m pointers to [vocab[j]][1] tables, or NULL (no linear part);
+ * cols     device int[m]: column of X that holds field j's id;   vocab: device int[m];
+ * dense_cols device int[nd] (may be NULL when nd == 0); dense_w [nd] (linear_model.weight);
+ * emb_fm   out, FM layout [m][B*D]   (the CIN input, reference layout [B,m,D]);
+ * dnn_in   out [B][m*D + nd] or NULL (combined_dnn_input);
+ * lin_out  out [B] or NULL           (linear_logit);
+ * err_flag device int[1] or NULL: bit 0 is OR-ed in when an id is outside [0, vocab) (the id is
+ *          then clamped; the reference raises IndexError / device-asserts).
+ */
+int xdfm_embed_gather_fwd(const float* X, long ldx, int B,
+                          const float* const* tables, const float* const* lin_tables,
+                          const int* cols, const int* vocab, int m, int D,
+                          const int* dense_cols, const float* dense_w, int nd,
+                          float* emb_fm, float* dnn_in, float* lin_out,
+                          int* err_flag, void* stream);
+
+/* ------------------------------------------------------------------ embedding scatter (K2)
+ * replaces: autograd of the above (aten::embedding_dense_backward x52, sparse=False,
+ *           deepctr/inputs.py:168) and d(linear_model.weight).
+ * d_emb_fm [m][B*D] or NULL, d_dnn_in [B][m*D+nd] or NULL, d_lin [B] or NULL are the incoming
+ * gradients; d_tables / d_lin_tables are device arrays of m pointers to ZERO-INITIALISED dense
+ * gradient tables which are accumulated into (fp32 atomics); d_dense_w [nd] is accumulated too.
+ */
+int xdfm_embed_scatter_bwd(const float* X, long ldx, int B,
+                           const int* cols, const int* vocab, int m, int D,
+                           const int* dense_cols, int nd,
+                           const float* d_emb_fm, const float* d_dnn_in, const float* d_lin,
+                           float* const* d_tables, float* const* d_lin_tables, float* d_dense_w,
+                           void* stream);
+
+/* ------------------------------------------------------------------ CIN level (K3 / K4)
+ * One level of deepctr/layers/interaction.py:216-243 (same loop in
+ * deepctr/layers/cin_attention.py:257-289, :417-446):
+ *     Z[b,(i,j),d] = x_prev[b,i,d] * x0[b,j,d]                 (einsum, :218-222, k = i*m + j)
+ *     out[b,h,d]   = act( sum_k W[h,k] * Z[b,k,d] + bias[h] )   (nn.Conv1d k=1 :224, act :226-229)
+ * Z is never materialised: it is formed in registers as the B operand of the MFMA contraction.
+ * W is conv1ds[i].weight [H][Hp*m] (the trailing 1 of Conv1d dropped), xp is [Hp][N], x0 [m][N],
+ * out [H][N], all FM layout, N = B*D.
+ */
+size_t xdfm_cin_fwd_pack_elems(int H, int Hp, int m);                 /* floats in Wf */
+int xdfm_cin_fwd_pack(const float* W, int H, int Hp, int m, float* Wf, void* stream);
+int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const float* bias,
+                       int H, int Hp, int m, long N, int act, float* out, void* stream);
+
+/* sum over the embedding axis of `rows` feature maps (interaction.py:245-246):
+ * res[b*ldres + off + r] = sum_d A[(row0 + r)][b*D + d] */
+int xdfm_cin_direct_sum(const float* A, int row0, int rows, int B, int D,
+                        float* res, long ldres, int off, void* stream);
+
+/* dOut = act'(A) * (dHid + dDirect), dbias[h] += sum_n dOut[h][n]   (autograd of :224-243).
+ * A [H][N] is the saved post-activation output of the level.  Rows [hid0, hid0+hid_rows) take
+ * dHid [hid_rows][N] (gradient w.r.t. next level's x_prev); rows [dir0, dir0+dir_rows) take the
+ * direct-connect gradient: dir_mode 0: dDir is d(result) [B][lddir], value dDir[b*lddir+dir_off+r]
+ * broadcast over d (sum pooling); dir_mode 1: dDir is FM layout [.][N], row dir_off + r
+ * (attention pooling).  Either part may be absent (rows == 0 / NULL).  dbias must be zeroed by the
+ * caller. */
+int xdfm_cin_dout(const float* A, int H, int B, int D, int act,
+                  const float* dHid, int hid0, int hid_rows,
+                  const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+                  float* dOut, float* dbias, void* stream);
+
+/* dx_prev[i][n] += sum_j dZ[(i,j)][n] * x0[j][n];  dx0[j][n] += sum_i dZ[(i,j)][n] * x_prev[i][n]
+ * with dZ = W^T dOut recomputed tile by tile.  dxp [Hp][N] and dx0 [m][N] are ACCUMULATED into
+ * (caller zero-initialises); dxp and dx0 must NOT alias (for level 0, where x_prev is x0, pass a
+ * scratch dxp and add it to dx0 afterwards).  H <= 256 rows of the contraction per call. */
+size_t xdfm_cin_bwd_pack_elems(int H, int Hp, int m);
+int xdfm_cin_bwd_pack(const float* W, int H, int Hp, int m, float* Wz, void* stream);
+int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz,
+                         int H, int Hp, int m, long N, float* dxp, float* dx0, void* stream);
+
+/* dW[h][i*m+j] = sum_n dOut[h][n] * x_prev[i][n] * x0[j][n]   (overwrites dW [H][Hp*m]).
+ * ws: workspace of xdfm_cin_bwd_w_ws_elems floats. */
+size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m);
+int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
+                         int H, int Hp, int m, long N, float* ws, float* dW, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XDFM_H */

@@ -1,0 +1,82 @@
+"""CPU: the C-ABI library loads and exports exactly what include/xdfm.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import PKG, ROOT
+
+HEADER = os.path.join(ROOT, "include", "xdfm.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(xdfm_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from xdfm_amd import _lib
+    lib = _lib.load()
+    names = _declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libxdfm_hip.so lacks %s" % n
+    assert sorted(_lib.SIGNATURES.keys()) == names, "python binding and header disagree"
+
+
+def test_abi_version_and_error_text():
+    from xdfm_amd import _lib
+    lib = _lib.load()
+    assert lib.xdfm_abi_version() == _lib.ABI_VERSION
+    assert isinstance(lib.xdfm_last_error(), bytes)
+    # argument validation happens before any device work, so it can be exercised without a GPU
+    rc = lib.xdfm_cin_level_fwd(None, None, None, None, 8, 4, 4, 64, 1, None, None)
+    assert rc == 1 and b"null pointer" in lib.xdfm_last_error()
+    with pytest.raises(ValueError):
+        _lib.check(rc, "cin_level_fwd")
+    assert lib.xdfm_set_option(b"no_such_key", 1) == 1
+    assert lib.xdfm_set_option(b"fwd_nf", 2) == 0 and lib.xdfm_get_option(b"fwd_nf") == 2
+    assert lib.xdfm_set_option(b"fwd_nf", 1) == 0
+
+
+def test_workspace_size_queries():
+    from xdfm_amd import _lib
+    lib = _lib.load()
+    # forward pack: MB * (Tpad + 4) * 64 * MT floats
+    assert lib.xdfm_cin_fwd_pack_elems(128, 128, 26) == 1 * (128 * 13 + 4) * 64 * 4
+    assert lib.xdfm_cin_fwd_pack_elems(256, 26, 26) == 1 * (340 + 4) * 64 * 8
+    assert lib.xdfm_cin_fwd_pack_elems(512, 26, 22) == 2 * (288 + 4) * 64 * 8
+    assert lib.xdfm_cin_bwd_pack_elems(128, 128, 26) == (4 * 26 * 16 + 3) * 256
+    assert lib.xdfm_cin_bwd_pack_elems(300, 4, 4) == 0          # > 256 rows per call is rejected
+    assert lib.xdfm_cin_bwd_w_ws_elems(128, 64, 26) == 26 * 128 * 64
+    assert lib.xdfm_cin_bwd_w_ws_elems(6, 5, 3) == 3 * 32 * 32
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from xdfm_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.XdfmError):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from xdfm_amd import ops
+    from deepctr.layers import CIN
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        CIN(3, (4,))(torch.zeros(2, 3, 4))
+    plan = ops.EmbedPlan([0], [4], [], 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.EmbedGather.apply(torch.zeros(2, 1), None, plan, False, torch.zeros(4, 4))
+
+
+def test_product_never_imports_oracle():
+    """The shipped package must not reference oracle/ (it is test infrastructure)."""
+    for base, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(base, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text, os.path.join(base, f)

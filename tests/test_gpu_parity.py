@@ -1,0 +1,310 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+(a) the golden vectors produced by the real reference and (b) the CPU oracle on seeded inputs.
+
+Tolerances (fp32 everywhere): forward values rtol 2e-5 / atol 2e-6 -- the MFMA contraction sums
+K = Hp*m products in a different order than ATen; gradients rtol 2e-4 with an absolute floor of
+2e-5 x max|expected| (dW sums B*D = thousands of terms with fp32 atomics in arbitrary order).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def close(got, want, rtol=2e-5, atol=2e-6, msg=""):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=atol, err_msg=msg)
+
+
+def gclose(got, want, msg=""):
+    want = np.asarray(want)
+    close(got, want, rtol=2e-4, atol=2e-5 * float(np.abs(want).max()) + 1e-9, msg=msg)
+
+
+# --------------------------------------------------------------------------------------------- #
+def test_native_library_is_loaded():
+    from xdfm_amd import _lib
+    lib = _lib.load()
+    assert lib.xdfm_abi_version() == 1
+    assert lib.xdfm_device_count() >= 1
+    with open("/proc/self/maps") as f:
+        assert "libxdfm_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("name", golden_names("cin_"))
+def test_cin_layer_vs_reference_golden(name):
+    from deepctr.layers import CIN
+    dev = _dev()
+    g = load_golden(name)
+    ls = tuple(int(v) for v in g["layer_size"])
+    B, m, D = g["x"].shape
+    layer = CIN(m, ls, str(g["activation"]), bool(g["split_half"]), 0.0, 1024, device=dev)
+    with torch.no_grad():
+        for i, c in enumerate(layer.conv1ds):
+            c.weight.copy_(T(g["w%d" % i]))
+            c.bias.copy_(T(g["b%d" % i]))
+    x = T(g["x"]).to(dev).requires_grad_(True)
+    out = layer(x)
+    close(out, g["out"], msg="out")
+    (out * T(g["gout"]).to(dev)).sum().backward()
+    gclose(x.grad, g["dx"], "dx")
+    for i, c in enumerate(layer.conv1ds):
+        gclose(c.weight.grad, g["dw%d" % i], "dw%d" % i)
+        gclose(c.bias.grad, g["db%d" % i], "db%d" % i)
+
+
+@pytest.mark.parametrize("B,m,D,ls", [(130, 26, 16, (64, 32, 32)), (37, 7, 10, (40, 24)), (257, 26, 8, (128, 128)),
+                                       (70, 5, 32, (24, 10, 6)), (33, 26, 16, (256,))])
+def test_cin_vs_oracle_random(B, m, D, ls):
+    from deepctr.layers import CIN
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    torch.manual_seed(B * 7 + m)
+    layer = CIN(m, ls, "relu", True, 0.0, 1024, device="cpu")
+    x = (torch.randn(B, m, D) * 0.6).requires_grad_(True)
+    W = [c.weight.detach().clone().requires_grad_(True) for c in layer.conv1ds]
+    Bs = [c.bias.detach().clone().requires_grad_(True) for c in layer.conv1ds]
+    want = orc.cin_forward(x, W, Bs, True, "relu")
+    gout = torch.randn(want.shape)
+    (want * gout).sum().backward()
+    layer = layer.to(dev)
+    xg = x.detach().to(dev).requires_grad_(True)
+    out = layer(xg)
+    close(out, want.detach().numpy(), msg="out")
+    (out * gout.to(dev)).sum().backward()
+    gclose(xg.grad, x.grad.numpy(), "dx")
+    for i, c in enumerate(layer.conv1ds):
+        gclose(c.weight.grad, W[i].grad.numpy(), "dw%d" % i)
+        gclose(c.bias.grad, Bs[i].grad.numpy(), "db%d" % i)
+
+
+def test_cin_rejects_bad_input_like_reference():
+    from deepctr.layers import CIN
+    dev = _dev()
+    layer = CIN(4, (8, 4), device=dev)
+    with pytest.raises(ValueError):
+        layer(torch.zeros(3, 4, device=dev))
+    with pytest.raises(ValueError):
+        CIN(4, ())
+    with pytest.raises(ValueError):
+        CIN(4, (7, 4))
+    with pytest.raises(RuntimeError):
+        CIN(4, (8, 4))(torch.zeros(2, 4, 8))       # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("name", golden_names("attn_"))
+def test_cin_attention_vs_reference_golden(name):
+    from deepctr.layers import CINAttention, CINAttentionV2
+    dev = _dev()
+    g = load_golden(name)
+    ls = tuple(int(v) for v in g["layer_size"])
+    B, m, D = g["x"].shape
+    kw = dict(num_heads=int(g["num_heads"]), use_layer_norm=bool(g["use_layer_norm"]),
+              use_residual=bool(g["use_residual"]))
+    if str(g["variant"]) == "attn":
+        layer = CINAttention(m, D, ls, "relu", True, attn_dropout=0.0, device=dev, **kw)
+    else:
+        layer = CINAttentionV2(m, D, ls, "relu", True, attn_dropout=0.0, num_attn_layers=int(g["num_attn_layers"]),
+                               device=dev, **kw)
+    sd = {k[2:]: T(v) for k, v in g.items() if k.startswith("p:")}
+    layer.load_state_dict(sd, strict=True)
+    x = T(g["x"]).to(dev).requires_grad_(True)
+    out = layer(x)
+    close(out, g["out"], rtol=5e-5, atol=5e-6, msg="out")
+    (out * T(g["gout"]).to(dev)).sum().backward()
+    gclose(x.grad, g["dx"], "dx")
+    for k, p in layer.named_parameters():
+        gclose(p.grad, g["g:" + k], k)
+
+
+# --------------------------------------------------------------------------------------------- #
+def _build_model(g, dev):
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr import models
+    vocab = [int(v) for v in g["vocab"]]
+    nd, D = int(g["n_dense"]), int(g["emb_dim"])
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)]
+    cols += [DenseFeat("I%d" % (i + 1), 1) for i in range(nd)]
+    kw = dict(zip([str(k) for k in g["kw_keys"]], [int(v) for v in g["kw_vals"]]))
+    cls = getattr(models, str(g["cls"]))
+    model = cls(cols, cols, dnn_hidden_units=tuple(int(v) for v in g["dnn"]),
+                cin_layer_size=tuple(int(v) for v in g["cin"]), l2_reg_dnn=1e-5, device=dev, **kw)
+    return model
+
+
+@pytest.mark.parametrize("name", golden_names("model_"))
+def test_model_vs_reference_golden(name):
+    dev = _dev()
+    g = load_golden(name)
+    model = _build_model(g, dev)
+    # same seed -> the reference's own initial weights (RNG order parity)
+    for k, v in model.state_dict().items():
+        want = g["init:" + k]
+        np.testing.assert_array_equal(v.cpu().numpy()[: want.shape[0]], want, err_msg="init " + k)
+    model.load_state_dict({k[3:]: T(v) for k, v in g.items() if k.startswith("s0:")}, strict=True)
+    B = int(g["B"])
+    X, y = T(g["X"]).to(dev), T(g["y"]).to(dev)
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+    model.train()
+    y_pred = model(X[:B])
+    close(y_pred, g["y_pred"], rtol=2e-5, atol=1e-6, msg="y_pred")
+    loss = torch.nn.functional.binary_cross_entropy(y_pred.squeeze(), y[:B].squeeze(), reduction="sum")
+    reg = model.get_regularization_loss()
+    assert abs(loss.item() - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    assert abs(reg.item() - float(g["reg"])) <= 1e-5 * abs(float(g["reg"]))
+    model.optim.zero_grad()
+    (loss + reg).backward()
+    for k, p in model.named_parameters():
+        gclose(p.grad, g["g:" + k], k)
+    model.optim.zero_grad()
+    # three Adam steps, as BaseModel.fit does them
+    losses = []
+    for s in range(3):
+        xb, yb = X[s * B:(s + 1) * B], y[s * B:(s + 1) * B]
+        yp = model(xb).squeeze()
+        model.optim.zero_grad()
+        l = torch.nn.functional.binary_cross_entropy(yp, yb.squeeze(), reduction="sum")
+        tot = l + model.get_regularization_loss() + model.aux_loss
+        losses.append([l.item(), tot.item()])
+        tot.backward()
+        model.optim.step()
+    np.testing.assert_allclose(np.array(losses), g["losses3"], rtol=2e-5)
+    for k, v in model.state_dict().items():
+        close(v, g["s3:" + k], rtol=1e-3, atol=2e-5, msg="after 3 steps: " + k)
+    names = list(model.feature_index.keys())
+    Xn = g["X"]
+    pred = model.predict({n: Xn[:, i] for i, n in enumerate(names)}, batch_size=B)
+    assert pred.dtype == np.float64 and pred.shape == (Xn.shape[0], 1)
+    # logloss / AUC within the north-star tolerance of 1e-5 against the reference's predictions
+    from xdfm_amd import metrics as M
+    yn = g["y"]
+    assert abs(M.log_loss(yn, pred) - M.log_loss(yn, g["pred_after"])) < 1e-5
+    assert abs(M.roc_auc_score(yn, pred) - M.roc_auc_score(yn, g["pred_after"])) < 1e-5
+
+
+def test_fit_history_vs_reference_golden():
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    dev = _dev()
+    g = load_golden("fit_history")
+    vocab, nd, D = [int(v) for v in g["vocab"]], int(g["n_dense"]), int(g["emb_dim"])
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)]
+    cols += [DenseFeat("I%d" % (i + 1), 1) for i in range(nd)]
+    model = xDeepFM(cols, cols, dnn_hidden_units=(8,), cin_layer_size=(6, 4), l2_reg_dnn=1e-5, device=dev)
+    for k, v in model.state_dict().items():
+        np.testing.assert_array_equal(v.cpu().numpy(), g["s0:" + k], err_msg=k)
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+    for pg in model.optim.param_groups:
+        pg["lr"] = 1e-2
+    names = list(model.feature_index.keys())
+    X, y, Xv, yv = g["X"], g["y"], g["Xv"], g["yv"]
+    hist = model.fit({n: X[:, i] for i, n in enumerate(names)}, y, batch_size=64, epochs=2, verbose=2,
+                     validation_data=({n: Xv[:, i] for i, n in enumerate(names)}, yv), shuffle=False)
+    keys = sorted(hist.history.keys())
+    assert keys == [str(k) for k in g["hist_keys"]]
+    got = np.array([hist.history[k] for k in keys])
+    np.testing.assert_allclose(got, g["hist_vals"], rtol=2e-4, atol=2e-5)
+    pred = model.predict({n: Xv[:, i] for i, n in enumerate(names)}, 32)
+    np.testing.assert_allclose(pred, g["pred"], rtol=2e-4, atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------- #
+def test_gather_scatter_vs_oracle():
+    """K1/K2 alone: ids incl. 0, vocab-1 and repeats; D not a multiple of 4; partial last block."""
+    from xdfm_amd import ops
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    for (B, vocab, nd, D) in [(37, [5, 9, 3, 17, 2], 3, 10), (300, [50] * 26, 13, 16), (1, [4, 4], 0, 3)]:
+        m = len(vocab)
+        X, _ = orc.synthetic_batch(B, vocab, nd, seed=B)
+        X[0, :m] = 0
+        X[-1, :m] = np.array(vocab) - 1
+        spec = orc.Spec(["C%d" % i for i in range(m)], vocab, ["I%d" % i for i in range(nd)], D)
+        g = torch.Generator().manual_seed(1)
+        st = {}
+        for n, v in zip(spec.sparse_names, vocab):
+            st["embedding_dict.%s.weight" % n] = torch.randn(v, D, generator=g).requires_grad_(True)
+            st["linear_model.embedding_dict.%s.weight" % n] = torch.randn(v, 1, generator=g).requires_grad_(True)
+        if nd:
+            st["linear_model.weight"] = torch.randn(nd, 1, generator=g).requires_grad_(True)
+        Xt = T(X)
+        emb = orc.embed_gather(Xt, st, spec)
+        lin = orc.linear_logit(Xt, st, spec)
+        dnn = orc.combined_dnn_input(emb, orc.dense_values(Xt, spec))
+        ge, gd, gl = torch.randn(emb.shape, generator=g), torch.randn(dnn.shape, generator=g), \
+            torch.randn(lin.shape, generator=g)
+        ((emb * ge).sum() + (dnn * gd).sum() + (lin * gl).sum()).backward()
+
+        plan = ops.EmbedPlan(list(range(m)), vocab, list(range(m, m + nd)), D)
+        tabs = [st["embedding_dict.%s.weight" % n].detach().to(dev).requires_grad_(True) for n in spec.sparse_names]
+        lins = [st["linear_model.embedding_dict.%s.weight" % n].detach().to(dev).requires_grad_(True)
+                for n in spec.sparse_names]
+        w = st["linear_model.weight"].detach().to(dev).requires_grad_(True) if nd else None
+        emb_fm, dnn_in, lin_out = ops.EmbedGather.apply(Xt.to(dev), w, plan, True, *tabs, *lins)
+        got_emb = ops.from_fm_layout(emb_fm, B, D)
+        np.testing.assert_array_equal(got_emb.detach().cpu().numpy(), emb.detach().numpy())
+        np.testing.assert_array_equal(dnn_in.detach().cpu().numpy(), dnn.detach().numpy())
+        close(lin_out, lin.detach().numpy(), rtol=1e-6, atol=1e-6)
+        ((got_emb * ge.to(dev)).sum() + (dnn_in * gd.to(dev)).sum() + (lin_out * gl.to(dev)).sum()).backward()
+        for n, t, l in zip(spec.sparse_names, tabs, lins):
+            gclose(t.grad, st["embedding_dict.%s.weight" % n].grad.numpy(), n)
+            gclose(l.grad, st["linear_model.embedding_dict.%s.weight" % n].grad.numpy(), "lin " + n)
+        if nd:
+            gclose(w.grad, st["linear_model.weight"].grad.numpy(), "dense w")
+        assert not plan.check_ids(dev)
+
+
+def test_gather_flags_out_of_range_ids():
+    from xdfm_amd import ops
+    dev = _dev()
+    plan = ops.EmbedPlan([0, 1], [4, 4], [], 4)
+    tabs = [torch.randn(4, 4, device=dev) for _ in range(2)]
+    X = torch.tensor([[1.0, 7.0], [0.0, 2.0]], device=dev)
+    ops.EmbedGather.apply(X, None, plan, False, *tabs)
+    assert plan.check_ids(dev)
+    assert not plan.check_ids(dev)
+
+
+def test_full_size_cin_rows_vs_oracle_subset():
+    """BASELINE config 2 shape (B=4096, m=26, D=16, cin=(256,128,128)): examples are independent,
+    so 48 rows of the full-size launch are compared with the oracle run on just those rows, and
+    gradients are checked through linearity: dW of the full batch restricted to a gout that is
+    zero outside the subset equals the oracle's dW on the subset."""
+    from deepctr.layers import CIN
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    B, m, D, ls = 4096, 26, 16, (256, 128, 128)
+    torch.manual_seed(5)
+    layer = CIN(m, ls, "relu", True, 0.0, 1024, device="cpu")
+    x = torch.randn(B, m, D) * 0.5
+    rows = torch.randperm(B)[:48]
+    W = [c.weight.detach().clone().requires_grad_(True) for c in layer.conv1ds]
+    Bs = [c.bias.detach().clone().requires_grad_(True) for c in layer.conv1ds]
+    xs = x[rows].clone().requires_grad_(True)
+    want = orc.cin_forward(xs, W, Bs, True, "relu")
+    gsub = torch.randn(want.shape)
+    (want * gsub).sum().backward()
+    layer = layer.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg)
+    close(out[rows.to(dev)], want.detach().numpy(), msg="out rows")
+    gout = torch.zeros(B, want.shape[1])
+    gout[rows] = gsub
+    (out * gout.to(dev)).sum().backward()
+    gclose(xg.grad[rows.to(dev)], xs.grad.numpy(), "dx rows")
+    mask = torch.ones(B, dtype=torch.bool)
+    mask[rows] = False
+    assert float(xg.grad[mask.to(dev)].abs().max()) == 0.0      # untouched examples get exactly zero
+    for i, c in enumerate(layer.conv1ds):
+        gclose(c.weight.grad, W[i].grad.numpy(), "dw%d" % i)
+        gclose(c.bias.grad, Bs[i].grad.numpy(), "db%d" % i)

@@ -1,0 +1,126 @@
+"""CPU: host-side mirror of the reference interface (feature columns, column map, CIN geometry,
+constructors / error behaviour, callbacks, metrics, state_dict contract)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def test_feature_columns_and_index():
+    from deepctr.inputs import DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, get_feature_names
+    s = SparseFeat("C1", 100, embedding_dim=8)
+    assert s.embedding_name == "C1" and s.group_name == "default_group" and s.dtype == "int32"
+    assert SparseFeat("C2", 10000, "auto").embedding_dim == 6 * int(pow(10000, 0.25))
+    assert hash(s) == hash("C1") and s == SparseFeat("C1", 100, 8)
+    d = DenseFeat("I1")
+    assert d.dimension == 1 and d.dtype == "float32"
+    cols = [SparseFeat("C%d" % i, 10, 4) for i in range(3)] + [DenseFeat("I1", 1), DenseFeat("I2", 2)]
+    idx = build_input_features(cols + cols)                     # linear_cols + dnn_cols, duplicates ignored
+    assert list(idx.items()) == [("C0", (0, 1)), ("C1", (1, 2)), ("C2", (2, 3)), ("I1", (3, 4)), ("I2", (4, 6))]
+    assert get_feature_names(cols) == ["C0", "C1", "C2", "I1", "I2"]
+    v = VarLenSparseFeat(SparseFeat("h", 5, 4), maxlen=3, length_name="hl")
+    assert list(build_input_features([v]).items()) == [("h", (0, 3)), ("hl", (3, 4))]
+    with pytest.raises(TypeError):
+        build_input_features([object()])
+
+
+def test_cin_geometry_matches_reference_field_nums():
+    from xdfm_amd.ops import cin_geometry
+    lv, fm = cin_geometry(26, (256, 128, 128), True)
+    assert fm == 320 and [(l[0], l[1]) for l in lv] == [(256, 26), (128, 128), (128, 64)]
+    assert [(l[2], l[3], l[4], l[5]) for l in lv] == [(128, 128, 128, 0), (64, 64, 64, 128), (0, 0, 128, 192)]
+    lv, fm = cin_geometry(4, (6, 5), False)
+    assert fm == 11 and [(l[0], l[1], l[2], l[4]) for l in lv] == [(6, 4, 6, 6), (5, 6, 5, 5)]
+    lv, fm = cin_geometry(3, (8, 5), True)
+    assert fm == 9 and lv[1][:2] == (5, 4)
+
+
+def test_constructor_contract_and_state_dict_keys():
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM, xDeepFMAttention, xDeepFMAttentionV2
+    cols = [SparseFeat("C%d" % (i + 1), 20, 16) for i in range(26)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(13)]
+    m = xDeepFM(cols, cols, cin_layer_size=(256, 128, 128))
+    sd = m.state_dict()
+    assert tuple(sd["cin.conv1ds.0.weight"].shape) == (256, 676, 1)
+    assert tuple(sd["cin.conv1ds.1.weight"].shape) == (128, 3328, 1)
+    assert tuple(sd["cin.conv1ds.2.weight"].shape) == (128, 1664, 1)
+    assert tuple(sd["cin_linear.weight"].shape) == (1, 320)
+    assert tuple(sd["dnn.linears.0.weight"].shape) == (256, 429)
+    assert tuple(sd["linear_model.weight"].shape) == (13, 1) and tuple(sd["out.bias"].shape) == (1,)
+    assert tuple(sd["linear_model.embedding_dict.C7.weight"].shape) == (20, 1)
+    assert m.featuremap_num == 320 and list(m.feature_index)[:2] == ["C1", "C2"]
+    a = xDeepFMAttention(cols, cols, cin_layer_size=(256, 128, 128))
+    for k in ("cin.mhsa.W_q.weight", "cin.layer_norm.weight", "cin.attn_pooling.attention.0.bias",
+              "cin.attn_pooling.attention.2.weight"):
+        assert k in a.state_dict()
+    assert tuple(a.state_dict()["cin.output_proj.weight"].shape) == (320, 16)
+    v2 = xDeepFMAttentionV2(cols, cols, cin_num_attn_layers=2)
+    assert "cin.mhsa_layers.1.W_o.weight" in v2.state_dict() and tuple(v2.state_dict()["cin_linear.weight"].shape) == (1, 16)
+    with pytest.raises(ValueError):
+        xDeepFM(cols, cols, gpus=[0])
+    with pytest.raises(ValueError):
+        xDeepFM(cols, cols, cin_layer_size=(7, 4))
+    with pytest.raises(NotImplementedError):
+        xDeepFM(cols, cols, cin_activation="prelu")
+    # regularisation groups (basemodel.py:126-127, xdeepfm.py:57-60,74-75)
+    groups = [(len(w), l2) for w, _, l2 in m.regularization_weight]
+    assert groups == [(26, 1e-5), (27, 1e-5), (2, 0), (1, 0), (3, 0)]
+    reg = m.get_regularization_loss()
+    want = sum(1e-5 * float((p ** 2).sum()) for n, p in m.named_parameters() if "embedding_dict" in n or n == "linear_model.weight")
+    assert abs(reg.item() - want) < 1e-6 * max(want, 1e-12) + 1e-12
+
+
+def test_metrics_vs_sklearn_golden():
+    from xdfm_amd import metrics as M
+    g = load_golden("metrics")
+    assert abs(M.log_loss(g["y"], g["p"]) - float(g["logloss"])) < 1e-12
+    assert abs(M.roc_auc_score(g["y"], g["p"]) - float(g["auc"])) < 1e-12
+    with pytest.raises(ValueError):
+        M.roc_auc_score(np.ones(4), np.arange(4))
+
+
+def test_callbacks_keras_semantics(tmp_path):
+    from deepctr.callbacks import CallbackList, EarlyStopping, History, ModelCheckpoint
+
+    class Dummy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(2))
+            self.stop_training = False
+    model = Dummy()
+    es = EarlyStopping(monitor="val_auc", patience=2, mode="max", verbose=0)
+    ck = ModelCheckpoint(str(tmp_path / "best.pth"), monitor="val_auc", save_best_only=True, save_weights_only=True,
+                         mode="max", verbose=0)
+    hist = History()
+    seen = []
+
+    class Duck(object):                         # the scripts' callbacks are duck-typed (xdftrain.py:31-97)
+        def on_epoch_end(self, epoch, logs=None):
+            seen.append(epoch)
+    cbs = CallbackList([es, ck, Duck(), hist])
+    cbs.set_model(model)
+    cbs.on_train_begin()
+    aucs = [0.6, 0.7, 0.65, 0.69, 0.5]
+    for e, a in enumerate(aucs):
+        with torch.no_grad():
+            model.w.fill_(float(e))
+        cbs.on_epoch_begin(e)
+        cbs.on_epoch_end(e, {"loss": 1.0 - a, "val_auc": a})
+        if model.stop_training:
+            break
+    cbs.on_train_end()
+    assert model.stop_training and es.stopped_epoch == 3 and seen == [0, 1, 2, 3]
+    assert hist.history["val_auc"] == aucs[:4] and hist.epoch == [0, 1, 2, 3]
+    best = torch.load(str(tmp_path / "best.pth"), weights_only=True)
+    assert float(best["w"][0]) == 1.0           # epoch index 1 had the best val_auc
+    assert EarlyStopping(monitor="val_loss").monitor_op == np.less
+    assert EarlyStopping(monitor="val_auc").monitor_op == np.greater
+
+
+def test_fm_layout_roundtrip():
+    from xdfm_amd import ops
+    x = torch.arange(2 * 3 * 4, dtype=torch.float32).view(2, 3, 4)
+    fm = ops.to_fm_layout(x)
+    assert fm.shape == (3, 8) and float(fm[1, 4 + 2]) == float(x[1, 1, 2])
+    assert torch.equal(ops.from_fm_layout(fm, 2, 4), x)

@@ -1,0 +1,397 @@
+// K4: backward of one CIN level (autograd of deepctr/layers/interaction.py:218-243).
+//
+//   dOut[h][n] = act'(A[h][n]) * (dHid[h][n] + dDirect)            cin_dout_kernel (+ dbias)
+//   dZ[(i,j)][n] = sum_h W[h][(i,j)] * dOut[h][n]                  cin_bwd_x_kernel  (MFMA, never stored)
+//      dxp[i][n] += sum_j dZ[(i,j)][n] * x0[j][n]
+//      dx0[j][n] += sum_i dZ[(i,j)][n] * xp[i][n]
+//   dW[h][(i,j)] = sum_n dOut[h][n] * xp[i][n] * x0[j][n]          cin_bwd_w_kernel  (MFMA, Z recomputed)
+//
+// The reference stores Z (1.5 GB per step at B=4096, D=16, cin=(256,128,128)) for these two
+// products; here both kernels rebuild their Z / dZ tiles in registers.
+#include "xdfm_internal.h"
+
+// =============================================================================================
+// dOut + dbias
+// =============================================================================================
+__global__ __launch_bounds__(256) void cin_dout_kernel(
+    const float* __restrict__ A, int H, long N, int D, int act,
+    const float* __restrict__ dHid, int hid0, int hid_rows,
+    const float* __restrict__ dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+    float* __restrict__ dOut, float* __restrict__ dbias) {
+    const int h = blockIdx.y;
+    const long nbase = (long)blockIdx.x * 1024;
+    const bool has_hid = dHid && h >= hid0 && h < hid0 + hid_rows;
+    const bool has_dir = dDir && h >= dir0 && h < dir0 + dir_rows;
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long n = nbase + k * 256 + threadIdx.x;
+        if (n < N) {
+            float g = 0.f;
+            if (has_hid) g += dHid[(long)(h - hid0) * N + n];
+            if (has_dir) {
+                if (dir_mode == 0) g += dDir[(n / D) * lddir + dir_off + (h - dir0)];
+                else g += dDir[(long)(dir_off + h - dir0) * N + n];
+            }
+            if (act == XDFM_ACT_RELU && !(A[(long)h * N + n] > 0.f)) g = 0.f;
+            dOut[(long)h * N + n] = g;
+            part += g;
+        }
+    }
+    // block reduction -> one atomic per block
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&dbias[h], wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+// =============================================================================================
+// dX kernel
+// =============================================================================================
+// Wz[g][lane][4], g = (iblk*m + j)*HS4 + q4: element e of lane (r = lane&31, s = lane>>5) is
+// W[h = 2*(4*q4+e) + s][k = (iblk*32 + r)*m + j]  (0 outside the matrix); BWX_PD zero groups appended.
+__global__ void cin_bwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, int HS4,
+                                    long total, long real_groups, float* __restrict__ Wz) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int e = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    const long g = idx >> 8;
+    float v = 0.f;
+    if (g < real_groups) {
+        const int q4 = (int)(g % HS4);
+        const long cj = g / HS4;
+        const int j = (int)(cj % m);
+        const int iblk = (int)(cj / m);
+        const int h = 2 * (4 * q4 + e) + (lane >> 5);
+        const int i = iblk * 32 + (lane & 31);
+        if (h < H && i < Hp) v = W[(long)h * ((long)Hp * m) + (long)i * m + j];
+    }
+    Wz[idx] = v;
+}
+
+template <int HS4>
+__global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
+    const float* __restrict__ dOut, const float* xp, const float* x0, const float* __restrict__ Wz,
+    int H, int Hp, int m, long N, int IB, float* dxp, float* dx0) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = lane & 31, s = lane >> 5;
+    const long n0 = ((long)blockIdx.x * 4 + wave) * 32;
+    if (n0 >= N) return;                       // wave-uniform, no barriers in this kernel
+    const long n = n0 + c;
+    const bool nok = n < N;
+    const long nc = nok ? n : N - 1;
+    const float nmask = nok ? 1.f : 0.f;
+
+    float* dx0s = smem + wave * (m * 32);      // wave-private accumulator for dx0[j][n0..n0+31]
+    for (int idx = lane; idx < m * 32; idx += 64) dx0s[idx] = 0.f;
+
+    // B operand for the whole kernel: dOut[h = 2q+s][n], q < 4*HS4, kept in registers
+    constexpr int NQ = 4 * HS4;
+    float breg[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int h = 2 * q + s;
+        const float v = dOut[(long)(h < H ? h : H - 1) * N + nc];
+        breg[q] = v * ((h < H) ? nmask : 0.f);
+    }
+
+    constexpr int R = HS4 >= 4 ? 4 : HS4;      // ring of float4 A groups
+    constexpr int PD = R - 1;
+    const f32x4* ap = reinterpret_cast<const f32x4*>(Wz) + lane;
+    f32x4 ring[R];
+#pragma unroll
+    for (int k = 0; k < PD; ++k) ring[k] = ap[(long)k * 64];
+    long g = 0;
+
+    for (int iblk = 0; iblk < IB; ++iblk) {
+        float xpr[16], dxa[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = iblk * 32 + frag_row(r, s);
+            const float v = xp[(long)(i < Hp ? i : Hp - 1) * N + nc];
+            xpr[r] = v * ((i < Hp) ? nmask : 0.f);
+            dxa[r] = 0.f;
+        }
+        for (int j = 0; j < m; ++j) {
+            const float x0j = x0[(long)j * N + nc] * nmask;    // consumed after the chain
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int q4 = 0; q4 < HS4; ++q4) {
+                ring[(q4 + PD) % R] = ap[(g + q4 + PD) * 64];
+                const f32x4 av = ring[q4 % R];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], breg[4 * q4 + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], breg[4 * q4 + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], breg[4 * q4 + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], breg[4 * q4 + 3], acc, 0, 0, 0);
+            }
+            g += HS4;
+            // acc[r] = dZ[(i = iblk*32 + frag_row(r,s), j)][n]
+            float sj = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dxa[r] = fmaf(acc[r], x0j, dxa[r]);
+                sj = fmaf(acc[r], xpr[r], sj);
+            }
+            sj += __shfl_xor(sj, 32);
+            if (s == 0) dx0s[j * 32 + c] += sj;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = iblk * 32 + frag_row(r, s);
+            if (i < Hp && nok) dxp[(long)i * N + n] += dxa[r];
+        }
+    }
+    // flush the wave's dx0 slice (dxp may alias dx0 for level 0: same wave, program order)
+    for (int idx = lane; idx < m * 32; idx += 64) {
+        const int j = idx >> 5;
+        const long nn = n0 + (idx & 31);
+        if (nn < N) dx0[(long)j * N + nn] += dx0s[idx];
+    }
+}
+
+// =============================================================================================
+// dW kernel
+// =============================================================================================
+#define BWW_NC 32
+#define BWW_PITCH 33
+// wave tile: 32*MT rows of h  x  (32 i's of block iblk) x JT values of j, accumulated over the
+// block's n range; result added (fp32 atomics, 128-B row segments) into
+// dWt[j][h][i]  (j < m, h < Hpad, i < IPAD) which cin_bwd_w_unpack_kernel turns into dW[h][i*m+j].
+template <int MT, int JT>
+__global__ __launch_bounds__(256, 2) void cin_bwd_w_kernel(
+    const float* __restrict__ dOut, const float* __restrict__ xp, const float* __restrict__ x0,
+    int H, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad, int IPAD,
+    float* __restrict__ dWt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int c = lane & 31, s = lane >> 5;
+    const int wt0 = blockIdx.x * 4;
+    const int hg = wt0 / TPH;                       // same for the 4 waves (TPH % 4 == 0)
+    const int tin = wt0 + wave - hg * TPH;
+    const bool active = tin < JP * IB;
+    const int jp = active ? tin / IB : 0;
+    const int iblk = active ? tin - jp * IB : 0;
+    const long n_begin = (long)blockIdx.y * n_per_split;
+    const long n_end = (n_begin + n_per_split < N) ? n_begin + n_per_split : N;
+
+    float* dOutS = smem;                                            // [32*MT][PITCH]
+    float* xpS = smem + 32 * MT * BWW_PITCH + wave * ((32 + JT) * BWW_PITCH);   // [32][PITCH]
+    float* x0S = xpS + 32 * BWW_PITCH;                              // [JT][PITCH]
+
+    f32x16 acc[MT][JT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][jt][r] = 0.f;
+
+    for (long nc0 = n_begin; nc0 < n_end; nc0 += BWW_NC) {
+        __syncthreads();                    // previous chunk fully consumed
+        {   // dOut rows of this h-group, 32 columns: thread -> (row = k*8 + tid/32, col = tid%32)
+            const int cc = tid & 31;
+            const long n = nc0 + cc;
+            const float cm = (n < n_end) ? 1.f : 0.f;
+            const long ncl = n < N ? n : N - 1;
+            float tmp[4 * MT];
+#pragma unroll
+            for (int k = 0; k < 4 * MT; ++k) {
+                const int rr = k * 8 + (tid >> 5);
+                const int h = hg * 32 * MT + rr;
+                tmp[k] = dOut[(long)(h < H ? h : H - 1) * N + ncl] * ((h < H) ? cm : 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 4 * MT; ++k) dOutS[(k * 8 + (tid >> 5)) * BWW_PITCH + cc] = tmp[k];
+        }
+        {   // this wave's 32 x_prev rows and JT x0 rows
+            const long n = nc0 + c;
+            const float cm = (n < n_end) ? 1.f : 0.f;
+            const long ncl = n < N ? n : N - 1;
+            float tmp[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = iblk * 32 + k * 2 + s;
+                tmp[k] = xp[(long)(i < Hp ? i : Hp - 1) * N + ncl] * ((i < Hp) ? cm : 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xpS[(k * 2 + s) * BWW_PITCH + c] = tmp[k];
+#pragma unroll
+            for (int k = 0; k < (JT + 1) / 2; ++k) {
+                const int jt = k * 2 + s;
+                if (jt < JT) {
+                    const int j = jp * JT + jt;
+                    x0S[jt * BWW_PITCH + c] = x0[(long)(j < m ? j : m - 1) * N + ncl] * ((j < m) ? cm : 0.f);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int t = 0; t < BWW_NC / 2; ++t) {
+            const int col = 2 * t + s;
+            float a[MT], b[JT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = dOutS[(mt * 32 + c) * BWW_PITCH + col];
+            const float xv = xpS[c * BWW_PITCH + col];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) b[jt] = xv * x0S[jt * BWW_PITCH + col];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[jt], acc[mt][jt], 0, 0, 0);
+        }
+    }
+
+    if (!active) return;
+    const int i = iblk * 32 + c;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j = jp * JT + jt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = hg * 32 * MT + mt * 32 + frag_row(r, s);
+                if (h < H && i < Hp && j < m)
+                    atomicAdd(&dWt[((long)j * Hpad + h) * IPAD + i], acc[mt][jt][r]);
+            }
+        }
+}
+
+__global__ void cin_bwd_w_unpack_kernel(const float* __restrict__ dWt, int H, int Hp, int m, int Hpad,
+                                        int IPAD, float* __restrict__ dW) {
+    const long K = (long)Hp * m;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)H * K) return;
+    const int h = (int)(idx / K);
+    const long k = idx - (long)h * K;
+    const int i = (int)(k / m), j = (int)(k - (long)i * m);
+    dW[idx] = dWt[((long)j * Hpad + h) * IPAD + i];
+}
+
+// =============================================================================================
+// host side
+// =============================================================================================
+static inline int bww_mt(int H) { return H > 64 ? 4 : (H > 32 ? 2 : 1); }
+#define BWW_JT 2
+
+template <int HS4>
+static int launch_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
+                        int m, long N, float* dxp, float* dx0, hipStream_t st) {
+    const int IB = ceil_div(Hp, 32);
+    const size_t lds = (size_t)4 * m * 32 * sizeof(float);
+    if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds);
+    hipLaunchKernelGGL((cin_bwd_x_kernel<HS4>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, Wz, H,
+                       Hp, m, N, IB, dxp, dx0);
+    return xdfm_check_launch("cin_level_bwd_x");
+}
+
+template <int MT>
+static int launch_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,
+                        float* ws, float* dW, hipStream_t st) {
+    constexpr int JT = BWW_JT;
+    const int IB = ceil_div(Hp, 32);
+    const int JP = ceil_div(m, JT);
+    const int TPH = (int)round_up((long)JP * IB, 4);
+    const int HG = ceil_div(H, 32 * MT);
+    const int Hpad = HG * 32 * MT;
+    const int IPAD = IB * 32;
+    const int gx = HG * TPH / 4;
+    int nsplit = xdfm_opt(OPT_BWW_NSPLIT);
+    const int max_split = ceil_div(N, BWW_NC);
+    if (nsplit <= 0) nsplit = ceil_div(1024, gx);
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > 65535) nsplit = 65535;
+    const long n_per_split = round_up(ceil_div(N, nsplit), BWW_NC);
+    nsplit = ceil_div(N, n_per_split);
+    const size_t ws_bytes = (size_t)m * Hpad * IPAD * sizeof(float);
+    hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, st);
+    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_level_bwd_w memset: %s", hipGetErrorString(e));
+    const size_t lds = (size_t)(32 * MT + 4 * (32 + JT)) * BWW_PITCH * sizeof(float);
+    hipLaunchKernelGGL((cin_bwd_w_kernel<MT, JT>), dim3(gx, nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp, m, N,
+                       IB, JP, TPH, n_per_split, Hpad, IPAD, ws);
+    int rc = xdfm_check_launch("cin_level_bwd_w");
+    if (rc) return rc;
+    const long total = (long)H * Hp * m;
+    hipLaunchKernelGGL(cin_bwd_w_unpack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, ws, H, Hp, m, Hpad,
+                       IPAD, dW);
+    return xdfm_check_launch("cin_level_bwd_w unpack");
+}
+
+extern "C" {
+
+int xdfm_cin_dout(const float* A, int H, int B, int D, int act, const float* dHid, int hid0, int hid_rows,
+                  const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+                  float* dOut, float* dbias, void* stream) {
+    XDFM_REQUIRE(A && dOut && dbias, "cin_dout: null pointer");
+    XDFM_REQUIRE(H > 0 && B > 0 && D > 0, "cin_dout: bad shape H=%d B=%d D=%d", H, B, D);
+    XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_dout: unsupported activation %d", act);
+    XDFM_REQUIRE(hid_rows >= 0 && dir_rows >= 0 && hid0 >= 0 && dir0 >= 0 && hid0 + hid_rows <= H &&
+                     dir0 + dir_rows <= H, "cin_dout: row ranges outside [0,%d)", H);
+    XDFM_REQUIRE(dir_mode == 0 || dir_mode == 1, "cin_dout: dir_mode %d", dir_mode);
+    const long N = (long)B * D;
+    hipLaunchKernelGGL(cin_dout_kernel, dim3(ceil_div(N, 1024), H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
+                       act, hid_rows > 0 ? dHid : nullptr, hid0, hid_rows, dir_rows > 0 ? dDir : nullptr, dir_mode,
+                       lddir, dir_off, dir0, dir_rows, dOut, dbias);
+    return xdfm_check_launch("cin_dout");
+}
+
+size_t xdfm_cin_bwd_pack_elems(int H, int Hp, int m) {
+    if (H <= 0 || Hp <= 0 || m <= 0 || H > 256) return 0;
+    return ((size_t)ceil_div(Hp, 32) * m * bwx_hs4(H) + BWX_PD) * 256;
+}
+
+int xdfm_cin_bwd_pack(const float* W, int H, int Hp, int m, float* Wz, void* stream) {
+    XDFM_REQUIRE(W && Wz, "cin_bwd_pack: null pointer");
+    XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0, "cin_bwd_pack: bad shape H=%d (<=256) Hp=%d m=%d", H, Hp, m);
+    const int HS4 = bwx_hs4(H);
+    const long real_groups = (long)ceil_div(Hp, 32) * m * HS4;
+    const long total = (real_groups + BWX_PD) * 256;
+    hipLaunchKernelGGL(cin_bwd_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, H, Hp,
+                       m, HS4, total, real_groups, Wz);
+    return xdfm_check_launch("cin_bwd_pack");
+}
+
+int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
+                         int m, long N, float* dxp, float* dx0, void* stream) {
+    XDFM_REQUIRE(dOut && xp && x0 && Wz && dxp && dx0, "cin_level_bwd_x: null pointer");
+    XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_x: bad shape H=%d (<=256) Hp=%d m=%d",
+                 H, Hp, m);
+    hipStream_t st = (hipStream_t)stream;
+    switch (bwx_hs4(H)) {
+        case 1: return launch_bwd_x<1>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
+        case 2: return launch_bwd_x<2>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
+        case 4: return launch_bwd_x<4>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
+        case 8: return launch_bwd_x<8>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
+        case 16: return launch_bwd_x<16>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
+        default: return launch_bwd_x<32>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
+    }
+}
+
+size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m) {
+    if (H <= 0 || Hp <= 0 || m <= 0) return 0;
+    const int MT = bww_mt(H);
+    return (size_t)m * (size_t)(ceil_div(H, 32 * MT) * 32 * MT) * (size_t)(ceil_div(Hp, 32) * 32);
+}
+
+int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,
+                         float* ws, float* dW, void* stream) {
+    XDFM_REQUIRE(dOut && xp && x0 && ws && dW, "cin_level_bwd_w: null pointer");
+    XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_w: bad shape H=%d Hp=%d m=%d", H, Hp, m);
+    hipStream_t st = (hipStream_t)stream;
+    switch (bww_mt(H)) {
+        case 1: return launch_bwd_w<1>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
+        case 2: return launch_bwd_w<2>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
+        default: return launch_bwd_w<4>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
+    }
+}
+
+}  // extern "C"

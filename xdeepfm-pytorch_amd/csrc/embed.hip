@@ -1,0 +1,187 @@
+// K1 / K2: sparse embedding gather (forward) and dense-gradient scatter (backward).
+//
+// replaces deepctr/models/basemodel.py:368-370 (26 x slice -> .long() -> nn.Embedding),
+// deepctr/models/basemodel.py:63-92 (Linear), deepctr/models/xdeepfm.py:86 and
+// deepctr/inputs.py:126-132 (the two concatenations) with ONE launch, and the 52
+// aten::embedding_dense_backward calls of their autograd with one more.
+//
+// Forward data flow per workgroup (EB consecutive examples):
+//   HBM rows --(16-B or 4-B loads, one row = D floats)--> LDS tile [EB][m][D]
+//   LDS tile --> dnn_in[b][0 .. m*D)        contiguous m*D floats per example
+//            --> emb_fm[j][b0*D .. (b0+EB)*D)  contiguous EB*D floats per field   (FM layout)
+// so both outputs are written in long contiguous runs although the rows arrive in id order.
+#include "xdfm_internal.h"
+
+#define EMB_THREADS 256
+
+template <int VEC>
+__global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
+    const float* __restrict__ X, long ldx, int B, const float* const* __restrict__ tables,
+    const float* const* __restrict__ lin_tables, const int* __restrict__ cols, const int* __restrict__ vocab,
+    int m, int D, const int* __restrict__ dense_cols, const float* __restrict__ dense_w, int nd, int EB,
+    float* __restrict__ emb_fm, float* __restrict__ dnn_in, float* __restrict__ lin_out, int* __restrict__ err_flag) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                          // [EB][m][D]
+    float* linv = smem + (size_t)EB * m * D;     // [EB][m]
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * EB;
+    const int nb = (B - b0 < EB) ? B - b0 : EB;
+    const int DV = D / VEC;
+    const long N = (long)B * D;
+
+    // phase 1: gather rows into the LDS tile (chunk = VEC floats of one row)
+    const int nchunks = nb * m * DV;
+    for (int idx = tid; idx < nchunks; idx += EMB_THREADS) {
+        const int q = idx % DV;
+        const int rj = idx / DV;                 // = bl*m + j
+        const int j = rj % m;
+        const int bl = rj / m;
+        const float fid = X[(long)(b0 + bl) * ldx + cols[j]];
+        long id = (long)fid;                     // truncation, as Tensor.long() (basemodel.py:369)
+        const int V = vocab[j];
+        if (id < 0 || id >= V) {
+            if (err_flag && q == 0) atomicOr(err_flag, 1);
+            id = id < 0 ? 0 : V - 1;
+        }
+        const float* src = tables[j] + id * D + q * VEC;
+        float* dst = tile + (size_t)rj * D + q * VEC;
+        if constexpr (VEC == 4) {
+            *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        } else if constexpr (VEC == 2) {
+            *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(src);
+        } else {
+            *dst = *src;
+        }
+        if (q == 0 && lin_tables) linv[rj] = lin_tables[j][id];
+    }
+    __syncthreads();
+
+    // phase 2a: dnn_in rows (sparse part is the tile verbatim, dense part copied from X)
+    if (dnn_in) {
+        const int ldd = m * D + nd;
+        const int per = m * D;
+        for (int idx = tid; idx < nb * per; idx += EMB_THREADS) {
+            const int bl = idx / per, k = idx - bl * per;
+            dnn_in[(long)(b0 + bl) * ldd + k] = tile[idx];
+        }
+        for (int idx = tid; idx < nb * nd; idx += EMB_THREADS) {
+            const int bl = idx / nd, k = idx - bl * nd;
+            dnn_in[(long)(b0 + bl) * ldd + per + k] = X[(long)(b0 + bl) * ldx + dense_cols[k]];
+        }
+    }
+    // phase 2b: FM layout, field-major: for field j the nb*D floats of this block are contiguous
+    {
+        const int per = nb * D;
+        for (int idx = tid; idx < m * per; idx += EMB_THREADS) {
+            const int j = idx / per, k = idx - j * per;     // k = bl*D + d
+            const int bl = k / D, d = k - bl * D;
+            emb_fm[(long)j * N + (long)b0 * D + k] = tile[((size_t)bl * m + j) * D + d];
+        }
+    }
+    // phase 2c: linear logit, summed in field order then dense columns in column order
+    if (lin_out && tid < nb) {
+        float acc = 0.f;
+        if (lin_tables)
+            for (int j = 0; j < m; ++j) acc += linv[tid * m + j];
+        float dacc = 0.f;
+        for (int k = 0; k < nd; ++k) dacc += X[(long)(b0 + tid) * ldx + dense_cols[k]] * dense_w[k];
+        lin_out[b0 + tid] = acc + dacc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: one thread per (b, j, d): atomic add of the row gradient into the dense table grad.
+__global__ __launch_bounds__(256) void embed_scatter_kernel(
+    const float* __restrict__ X, long ldx, int B, const int* __restrict__ cols, const int* __restrict__ vocab, int m,
+    int D, int nd, const float* __restrict__ d_emb_fm, const float* __restrict__ d_dnn_in,
+    const float* __restrict__ d_lin, float* const* __restrict__ d_tables, float* const* __restrict__ d_lin_tables) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * m * D;
+    if (idx >= total) return;
+    const int d = (int)(idx % D);
+    const long r = idx / D;
+    const int j = (int)(r % m);
+    const int b = (int)(r / m);
+    long id = (long)X[(long)b * ldx + cols[j]];
+    const int V = vocab[j];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    float g = 0.f;
+    if (d_emb_fm) g += d_emb_fm[((long)j * B + b) * D + d];
+    if (d_dnn_in) g += d_dnn_in[(long)b * ((long)m * D + nd) + (long)j * D + d];
+    if (d_tables) atomicAdd(d_tables[j] + id * D + d, g);
+    if (d == 0 && d_lin && d_lin_tables) atomicAdd(d_lin_tables[j] + id, d_lin[b]);
+}
+
+// d(linear_model.weight)[k] += sum_b X[b][dense_cols[k]] * d_lin[b]
+__global__ __launch_bounds__(256) void dense_w_grad_kernel(const float* __restrict__ X, long ldx, int B,
+                                                          const int* __restrict__ dense_cols, int nd,
+                                                          const float* __restrict__ d_lin,
+                                                          float* __restrict__ d_dense_w) {
+    const int k = blockIdx.y;
+    const int col = dense_cols[k];
+    float part = 0.f;
+    for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long)gridDim.x * blockDim.x)
+        part += X[b * ldx + col] * d_lin[b];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&d_dense_w[k], wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+extern "C" {
+
+int xdfm_embed_gather_fwd(const float* X, long ldx, int B, const float* const* tables,
+                          const float* const* lin_tables, const int* cols, const int* vocab, int m, int D,
+                          const int* dense_cols, const float* dense_w, int nd, float* emb_fm, float* dnn_in,
+                          float* lin_out, int* err_flag, void* stream) {
+    XDFM_REQUIRE(X && tables && cols && vocab && emb_fm, "embed_gather_fwd: null pointer");
+    XDFM_REQUIRE(B > 0 && m > 0 && D > 0 && nd >= 0 && ldx >= m + nd, "embed_gather_fwd: bad shape B=%d m=%d D=%d nd=%d ldx=%ld",
+                 B, m, D, nd, ldx);
+    XDFM_REQUIRE(nd == 0 || dense_cols, "embed_gather_fwd: dense_cols missing");
+    XDFM_REQUIRE(!(lin_out && nd > 0) || dense_w, "embed_gather_fwd: dense_w missing");
+    // examples per block: tile <= 32 KiB, at most 16, at least 1
+    int EB = (int)(8192 / ((long)m * D));
+    if (EB > 16) EB = 16;
+    if (EB < 1) EB = 1;
+    const size_t lds = ((size_t)EB * m * D + (size_t)EB * m) * sizeof(float);
+    XDFM_REQUIRE(lds <= 160 * 1024, "embed_gather_fwd: m*D=%ld too large for one LDS tile", (long)m * D);
+    XDFM_REQUIRE(EB <= EMB_THREADS, "embed_gather_fwd: internal");
+    dim3 grid(ceil_div(B, EB));
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(V)                                                                                              \
+    hipLaunchKernelGGL((embed_gather_kernel<V>), grid, dim3(EMB_THREADS), lds, st, X, ldx, B, tables, lin_tables, \
+                       cols, vocab, m, D, dense_cols, dense_w, nd, EB, emb_fm, dnn_in, lin_out, err_flag)
+    if (D % 4 == 0) LAUNCH(4);
+    else if (D % 2 == 0) LAUNCH(2);
+    else LAUNCH(1);
+#undef LAUNCH
+    return xdfm_check_launch("embed_gather_fwd");
+}
+
+int xdfm_embed_scatter_bwd(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
+                           const int* dense_cols, int nd, const float* d_emb_fm, const float* d_dnn_in,
+                           const float* d_lin, float* const* d_tables, float* const* d_lin_tables,
+                           float* d_dense_w, void* stream) {
+    XDFM_REQUIRE(X && cols && vocab, "embed_scatter_bwd: null pointer");
+    XDFM_REQUIRE(B > 0 && m > 0 && D > 0 && nd >= 0, "embed_scatter_bwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    if (d_tables || (d_lin && d_lin_tables)) {
+        const long total = (long)B * m * D;
+        hipLaunchKernelGGL(embed_scatter_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, X, ldx, B, cols, vocab,
+                           m, D, nd, d_emb_fm, d_dnn_in, d_lin, d_tables, d_lin_tables);
+        int rc = xdfm_check_launch("embed_scatter_bwd");
+        if (rc) return rc;
+    }
+    if (nd > 0 && d_lin && d_dense_w) {
+        XDFM_REQUIRE(dense_cols, "embed_scatter_bwd: dense_cols missing");
+        int gx = ceil_div(B, 256);
+        if (gx > 64) gx = 64;
+        hipLaunchKernelGGL(dense_w_grad_kernel, dim3(gx, nd), dim3(256), 0, st, X, ldx, B, dense_cols, nd, d_lin,
+                           d_dense_w);
+        return xdfm_check_launch("embed_scatter_bwd dense_w");
+    }
+    return XDFM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// Shared helpers for the libxdfm_hip translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/xdfm.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define XDFM_WAVE 64
+
+// error plumbing (api.hip)
+int xdfm_fail(int code, const char* fmt, ...);
+int xdfm_opt(int idx);
+enum {
+    OPT_FWD_NF = 0,      // column fragments (32 cols each) per wave in the forward kernel: 1 or 2
+    OPT_BWW_NSPLIT,      // 0 = auto; n-range splits of the dW kernel
+    OPT_BWW_SLAB,        // 1 = deterministic slab reduction instead of atomics (reserved)
+    OPT_COUNT
+};
+
+#define XDFM_REQUIRE(cond, ...) \
+    do { if (!(cond)) return xdfm_fail(XDFM_ERR_INVALID, __VA_ARGS__); } while (0)
+
+static inline int xdfm_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return XDFM_OK;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+// ---- geometry shared by pack and compute kernels --------------------------------------------
+// Forward: the wave's output tile is (32*MT rows) x (32*NF cols); MT is a function of H only so
+// that xdfm_cin_fwd_pack and xdfm_cin_level_fwd agree on the packed layout.
+static inline int fwd_mt(int H) {
+    int t = ceil_div(H, 32);
+    if (t >= 8) return 8;
+    if (t > 2) return 4;
+    return t;            // 1 or 2
+}
+#define FWD_PD 3          // A-fragment prefetch distance in k-steps (ring of 4)
+#define BWX_PD 3          // A-group prefetch distance in the dX kernel (ring of 4 float4)
+static inline int fwd_mp(int m) { return (m + 1) / 2; }                       // j-pairs per i
+static inline long fwd_tpad(int Hp, int m) { return round_up((long)Hp * fwd_mp(m), 4); }
+static inline int bwx_hs4(int H) {      // float4 groups along the contraction (h) axis
+    int g = ceil_div(H, 8);
+    int p = 1;
+    while (p < g) p <<= 1;
+    return p;                            // 1,2,4,...,32
+}
+
+// C/D fragment of v_mfma_f32_32x32x2_f32: register r of lane (c = lane&31, s = lane>>5)
+// holds element [row = (r&3) + 8*(r>>2) + 4*s][col = c].
+__device__ __forceinline__ int frag_row(int r, int s) { return (r & 3) + 8 * (r >> 2) + 4 * s; }

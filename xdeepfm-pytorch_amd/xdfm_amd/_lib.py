@@ -1,0 +1,80 @@
+"""ctypes binding of libxdfm_hip.so (the C ABI declared in include/xdfm.h).
+
+There is deliberately no fallback: if the shared library is missing or lacks a symbol the
+import of any op fails with an explicit error, and every op refuses non-CUDA tensors.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("XDFM_LIB", os.path.join(_HERE, "libxdfm_hip.so"))
+
+P = c_void_p
+# name -> (restype, argtypes); mirrors include/xdfm.h one to one
+SIGNATURES = {
+    "xdfm_abi_version": (c_int, []),
+    "xdfm_last_error": (c_char_p, []),
+    "xdfm_device_count": (c_int, []),
+    "xdfm_set_option": (c_int, [c_char_p, c_int]),
+    "xdfm_get_option": (c_int, [c_char_p]),
+    "xdfm_embed_gather_fwd": (c_int, [P, c_long, c_int, P, P, P, P, c_int, c_int, P, P, c_int, P, P, P, P, P]),
+    "xdfm_embed_scatter_bwd": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P]),
+    "xdfm_cin_fwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
+    "xdfm_cin_fwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "xdfm_cin_level_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_int, P, P]),
+    "xdfm_cin_direct_sum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_long, c_int, P]),
+    "xdfm_cin_dout": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int,
+                              c_int, P, P, P]),
+    "xdfm_cin_bwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
+    "xdfm_cin_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "xdfm_cin_level_bwd_x": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
+    "xdfm_cin_bwd_w_ws_elems": (c_size_t, [c_int, c_int, c_int]),
+    "xdfm_cin_level_bwd_w": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
+}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class XdfmError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library once, bind every symbol of include/xdfm.h, check the ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise XdfmError(
+            "libxdfm_hip.so not found at %s -- build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback for the xDeepFM hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise XdfmError("libxdfm_hip.so at %s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.xdfm_abi_version() != ABI_VERSION:
+        raise XdfmError("libxdfm_hip.so ABI %d != binding ABI %d" % (lib.xdfm_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().xdfm_last_error().decode("utf-8", "replace")
+        if rc == 1:
+            raise ValueError("xdfm %s: %s" % (what, msg))
+        raise XdfmError("xdfm %s failed (code %d): %s" % (what, rc, msg))
+
+
+def set_option(key, value):
+    check(load().xdfm_set_option(key.encode(), int(value)), "set_option")
+
+
+def get_option(key):
+    return load().xdfm_get_option(key.encode())

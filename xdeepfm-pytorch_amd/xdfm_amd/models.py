@@ -1,0 +1,522 @@
+"""xDeepFM model family on the MI355X kernels, behind the reference's Keras-like API.
+
+Public surface (names, positional order, defaults, state_dict keys) follows
+deepctr/models/basemodel.py:95-527, deepctr/models/xdeepfm.py:17-107 and
+deepctr/models/xdeepfm_attn.py:25-301 so that the xdftrain*.py flows run unchanged:
+`Model(linear_cols, dnn_cols, ...)`, `compile`, `fit`, `evaluate`, `predict`, `state_dict`.
+
+What differs underneath: `forward` is one fused gather launch (embeddings in FM layout, DNN input
+and linear logit together), the CIN stack on MFMA kernels, and a handful of tiny torch GEMMs; with
+torch.distributed initialised (one process per GPU, RCCL) `fit` shards every global batch row-wise
+over the ranks (xdfm_amd/dist.py).
+"""
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.data as Data
+from torch.utils.data import DataLoader
+
+from . import dist as xdist
+from . import metrics as M
+from . import ops
+from .callbacks import CallbackList, History
+from .inputs import (DenseFeat, SparseFeat, VarLenSparseFeat, build_input_features, create_embedding_matrix,
+                     split_columns)
+from .layers import CIN, DNN, CINAttention, CINAttentionV2, PredictionLayer
+
+try:
+    from tqdm import tqdm
+except ImportError:  # pragma: no cover
+    tqdm = None
+
+
+def _slice(arrays, start=None, stop=None):
+    """x[start:stop] for one array or each array of a list (deepctr/layers/utils.py:19-70 as fit uses it)."""
+    if isinstance(arrays, (list, tuple)):
+        return [None if a is None else a[start:stop] for a in arrays]
+    return arrays[start:stop]
+
+
+def _reject_varlen(cols):
+    if any(isinstance(c, VarLenSparseFeat) for c in cols):
+        raise NotImplementedError("VarLenSparseFeat is outside the xDeepFM hot path (no reference script uses it)")
+
+
+class Linear(nn.Module):
+    """Parameters of the linear part: one [vocab,1] table per sparse field and a [n_dense,1] weight
+    (deepctr/models/basemodel.py:34-92).  Inside the models its logit comes out of the fused gather;
+    calling the module directly runs the same kernel for the linear part alone."""
+
+    def __init__(self, feature_columns, feature_index, init_std=0.0001, device='cpu'):
+        super().__init__()
+        self.feature_index = feature_index
+        self.device = device
+        self.sparse_feature_columns, self.dense_feature_columns, self.varlen_sparse_feature_columns = \
+            split_columns(feature_columns)
+        _reject_varlen(self.varlen_sparse_feature_columns)
+        self.embedding_dict = create_embedding_matrix(feature_columns, init_std, linear=True, sparse=False,
+                                                      device=device)
+        for emb in self.embedding_dict.values():          # second draw, basemodel.py:55-56
+            nn.init.normal_(emb.weight, mean=0, std=init_std)
+        n_dense = sum(fc.dimension for fc in self.dense_feature_columns)
+        if n_dense > 0:
+            self.weight = nn.Parameter(torch.Tensor(n_dense, 1).to(device))
+            nn.init.normal_(self.weight, mean=0, std=init_std)
+        self._plan = None
+
+    def tables(self):
+        return [self.embedding_dict[fc.embedding_name].weight for fc in self.sparse_feature_columns]
+
+    def forward(self, X, sparse_feat_refine_weight=None):
+        if sparse_feat_refine_weight is not None:
+            raise NotImplementedError("refine weights belong to IFM/DIFM, not to the xDeepFM path")
+        if self._plan is None:
+            dense_cols = [c for fc in self.dense_feature_columns for c in range(*self.feature_index[fc.name])]
+            self._plan = ops.EmbedPlan([self.feature_index[fc.name][0] for fc in self.sparse_feature_columns],
+                                       [fc.vocabulary_size for fc in self.sparse_feature_columns], dense_cols, 1)
+        if not self.sparse_feature_columns:
+            out = torch.zeros([X.shape[0], 1], device=X.device)
+            if self.dense_feature_columns:
+                cols = self._plan.dense_cols
+                out = out + X[:, cols].matmul(self.weight)
+            return out
+        tabs = self.tables()
+        w = self.weight if self.dense_feature_columns else None
+        _, _, lin = ops.EmbedGather.apply(X, w, self._plan, True, *tabs, *tabs)
+        return lin
+
+
+class BaseModel(nn.Module):
+    def __init__(self, linear_feature_columns, dnn_feature_columns, l2_reg_linear=1e-5, l2_reg_embedding=1e-5,
+                 init_std=0.0001, seed=1024, task='binary', device='cpu', gpus=None):
+        super().__init__()
+        torch.manual_seed(seed)                              # basemodel.py:100
+        if gpus:
+            raise ValueError("`gpus=` (single-process nn.DataParallel, basemodel.py:206-209) is replaced by one "
+                             "process per GPU: launch with torch.distributed.run and leave gpus=None")
+        self.dnn_feature_columns = dnn_feature_columns
+        self.linear_feature_columns = linear_feature_columns
+        self.device = device
+        self.gpus = gpus
+        self.reg_loss = torch.zeros((1,), device=device)
+        self.aux_loss = torch.zeros((1,), device=device)
+        _reject_varlen(list(linear_feature_columns) + list(dnn_feature_columns))
+        self.feature_index = build_input_features(list(linear_feature_columns) + list(dnn_feature_columns))
+        self.embedding_dict = create_embedding_matrix(dnn_feature_columns, init_std, sparse=False, device=device)
+        self.linear_model = Linear(linear_feature_columns, self.feature_index, device=device)
+        self.regularization_weight = []
+        self.add_regularization_weight(self.embedding_dict.parameters(), l2=l2_reg_embedding)
+        self.add_regularization_weight(self.linear_model.parameters(), l2=l2_reg_linear)
+        self.out = PredictionLayer(task, )
+        self.to(device)
+        self._is_graph_network = True       # attributes Keras callbacks look at (basemodel.py:133-135)
+        self._ckpt_saved_epoch = False
+        self.history = History()
+        self.stop_training = False
+        self._plan = None
+
+    # ------------------------------------------------------------------ fused input stage
+    def _gather_plan(self):
+        if self._plan is None:
+            sparse, dense, _ = split_columns(self.dnn_feature_columns)
+            dims = {fc.embedding_dim for fc in sparse}
+            if len(dims) > 1:
+                raise ValueError("embedding_dim of SparseFeat and VarlenSparseFeat must be same in this model!")
+            lin_sparse = self.linear_model.sparse_feature_columns
+            self._fused_linear = [fc.name for fc in lin_sparse] == [fc.name for fc in sparse] and \
+                [fc.name for fc in self.linear_model.dense_feature_columns] == [fc.name for fc in dense]
+            dense_cols = [c for fc in dense for c in range(*self.feature_index[fc.name])]
+            self._plan = ops.EmbedPlan([self.feature_index[fc.name][0] for fc in sparse],
+                                       [fc.vocabulary_size for fc in sparse], dense_cols,
+                                       dims.pop() if dims else 1)
+            self._sparse_cols = sparse
+            dp = xdist.current()
+            if dp is not None and self._fused_linear:
+                # these gradients are built from the all-gathered rows and are identical on every rank
+                self._plan.dp = dp
+                dp.mark_replicated([self.embedding_dict[fc.embedding_name].weight for fc in sparse])
+                dp.mark_replicated(self.linear_model.parameters())
+        return self._plan
+
+    def fused_inputs(self, X):
+        """(emb_fm [m, B*D], dnn_in [B, m*D+nd], linear_logit [B,1]) from ONE gather launch
+        (input_from_feature_columns + linear_model + both concatenations of the reference forward)."""
+        plan = self._gather_plan()
+        if not self._sparse_cols:
+            raise NotImplementedError("the xDeepFM path needs at least one SparseFeat")
+        tabs = [self.embedding_dict[fc.embedding_name].weight for fc in self._sparse_cols]
+        if self._fused_linear:
+            w = getattr(self.linear_model, "weight", None)
+            return ops.EmbedGather.apply(X, w, plan, True, *tabs, *self.linear_model.tables())
+        emb_fm, dnn_in, _ = ops.EmbedGather.apply(X, None, plan, False, *tabs)
+        return emb_fm, dnn_in, self.linear_model(X)
+
+    def input_from_feature_columns(self, X, feature_columns, embedding_dict, support_dense=True):
+        """API of basemodel.py:354-380: ([B,1,D] per sparse field, [B,k] per dense field)."""
+        sparse, dense, varlen = split_columns(feature_columns)
+        _reject_varlen(varlen)
+        if not support_dense and len(dense) > 0:
+            raise ValueError("DenseFeat is not supported in dnn_feature_columns")
+        emb_list = []
+        if sparse:
+            plan = ops.EmbedPlan([self.feature_index[fc.name][0] for fc in sparse],
+                                 [fc.vocabulary_size for fc in sparse], [], sparse[0].embedding_dim)
+            tabs = [embedding_dict[fc.embedding_name].weight for fc in sparse]
+            emb_fm, _, _ = ops.EmbedGather.apply(X, None, plan, False, *tabs)
+            B = X.shape[0]
+            emb_list = [emb_fm[j].view(B, 1, plan.D) for j in range(plan.m)]
+        dense_list = [X[:, self.feature_index[fc.name][0]:self.feature_index[fc.name][1]] for fc in dense]
+        return emb_list, dense_list
+
+    def compute_input_dim(self, feature_columns, include_sparse=True, include_dense=True, feature_group=False):
+        sparse, dense, varlen = split_columns(feature_columns)
+        sparse = sparse + varlen
+        dim = 0
+        if include_sparse:
+            dim += len(sparse) if feature_group else sum(fc.embedding_dim for fc in sparse)
+        if include_dense:
+            dim += sum(fc.dimension for fc in dense)
+        return dim
+
+    @property
+    def embedding_size(self):
+        sparse, _, varlen = split_columns(self.dnn_feature_columns)
+        sizes = {fc.embedding_dim for fc in sparse + varlen}
+        if len(sizes) > 1:
+            raise ValueError("embedding_dim of SparseFeat and VarlenSparseFeat must be same in this model!")
+        return list(sizes)[0]
+
+    # ------------------------------------------------------------------ regularisation
+    def add_regularization_weight(self, weight_list, l1=0.0, l2=0.0):
+        weight_list = [weight_list] if isinstance(weight_list, nn.parameter.Parameter) else list(weight_list)
+        self.regularization_weight.append((weight_list, l1, l2))
+
+    def get_regularization_loss(self):
+        """sum over groups of l1*|w| + l2*w^2 (basemodel.py:412-428), shape [1]."""
+        total = torch.zeros((1,), device=self.device)
+        for weight_list, l1, l2 in self.regularization_weight:
+            for w in weight_list:
+                p = w[1] if isinstance(w, tuple) else w
+                if l1 > 0:
+                    total = total + torch.sum(l1 * torch.abs(p))
+                if l2 > 0:
+                    total = total + torch.sum(l2 * torch.square(p))
+        return total
+
+    def add_auxiliary_loss(self, aux_loss, alpha):
+        self.aux_loss = aux_loss * alpha
+
+    # ------------------------------------------------------------------ compile
+    def compile(self, optimizer, loss=None, metrics=None):
+        self.metrics_names = ["loss"]
+        self.optim = self._get_optim(optimizer)
+        self.loss_func = self._get_loss_func(loss)
+        self.metrics = self._get_metrics(metrics)
+
+    def _get_optim(self, optimizer):
+        if not isinstance(optimizer, str):
+            return optimizer
+        table = {"sgd": lambda p: torch.optim.SGD(p, lr=0.01), "adam": torch.optim.Adam,
+                 "adagrad": torch.optim.Adagrad, "rmsprop": torch.optim.RMSprop}
+        if optimizer not in table:
+            raise NotImplementedError
+        return table[optimizer](self.parameters())
+
+    def _get_loss_func(self, loss):
+        names = {"binary_crossentropy": F.binary_cross_entropy, "mse": F.mse_loss, "mae": F.l1_loss}
+
+        def one(name):
+            if name not in names:
+                raise NotImplementedError
+            return names[name]
+        if isinstance(loss, str):
+            return one(loss)
+        if isinstance(loss, list):
+            return [one(l) for l in loss]
+        return loss
+
+    @staticmethod
+    def _accuracy_score(y_true, y_pred):
+        return M.accuracy_score(y_true, np.where(y_pred > 0.5, 1, 0))
+
+    def _get_metrics(self, metrics, set_eps=False):
+        out = {}
+        for name in (metrics or []):
+            if name in ("binary_crossentropy", "logloss"):
+                out[name] = M.log_loss
+            if name == "auc":
+                out[name] = M.roc_auc_score
+            if name == "mse":
+                out[name] = M.mean_squared_error
+            if name in ("accuracy", "acc"):
+                out[name] = self._accuracy_score
+            self.metrics_names.append(name)
+        return out
+
+    def _in_multi_worker_mode(self):
+        return None
+
+    # ------------------------------------------------------------------ data plumbing
+    def _as_matrix(self, x):
+        """dict / list of per-feature arrays -> one [N, n_cols] array in feature_index order
+        (basemodel.py:155-156,191-197)."""
+        if isinstance(x, dict):
+            x = [x[name] for name in self.feature_index]
+        x = [np.expand_dims(a, axis=1) if len(a.shape) == 1 else a for a in x]
+        return np.concatenate(x, axis=-1)
+
+    # ------------------------------------------------------------------ fit / evaluate / predict
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, initial_epoch=0, validation_split=0.,
+            validation_data=None, shuffle=True, callbacks=None):
+        """Training loop with the observable behaviour of basemodel.py:137-309: same batch order for a
+        given torch seed (the stock DataLoader draws it), BCE(sum) + L2, History keys, callbacks."""
+        if isinstance(x, dict):
+            x = [x[name] for name in self.feature_index]
+        do_validation = False
+        val_x, val_y = [], []
+        if validation_data:
+            do_validation = True
+            if len(validation_data) == 2:
+                val_x, val_y = validation_data
+            elif len(validation_data) == 3:
+                val_x, val_y, _ = validation_data
+            else:
+                raise ValueError('When passing a `validation_data` argument, it must contain either 2 items '
+                                 '(x_val, y_val), or 3 items (x_val, y_val, val_sample_weights). '
+                                 'However we received `validation_data=%s`' % (validation_data,))
+            if isinstance(val_x, dict):
+                val_x = [val_x[name] for name in self.feature_index]
+        elif validation_split and 0. < validation_split < 1.:
+            do_validation = True
+            n0 = x[0].shape[0] if hasattr(x[0], 'shape') else len(x[0])
+            split_at = int(n0 * (1. - validation_split))
+            x, val_x = _slice(x, 0, split_at), _slice(x, split_at)
+            y, val_y = _slice(y, 0, split_at), _slice(y, split_at)
+
+        data = Data.TensorDataset(torch.from_numpy(self._as_matrix(x)), torch.from_numpy(y))
+        if batch_size is None:
+            batch_size = 256
+        model = self.train()
+        loss_func, optim = self.loss_func, self.optim
+        dp = xdist.current()
+        if dp is not None and verbose > 0:
+            print("row-parallel on %d ranks (RCCL), global batch %d" % (dp.world, batch_size * dp.world))
+        if dp is None:
+            print(self.device)
+        global_bs = batch_size * (dp.world if dp is not None else 1)   # `batch_size` is per GPU, as basemodel.py:209
+        loader = DataLoader(dataset=data, shuffle=shuffle, batch_size=global_bs)
+        sample_num = len(data)
+        steps_per_epoch = (sample_num - 1) // global_bs + 1
+
+        cbs = CallbackList((callbacks or []) + [self.history])
+        cbs.set_model(self)
+        cbs.on_train_begin()
+        cbs.set_model(self)
+        self.stop_training = False
+        print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
+            len(data), len(val_y), steps_per_epoch))
+        for epoch in range(initial_epoch, epochs):
+            cbs.on_epoch_begin(epoch)
+            epoch_logs, train_result = {}, {}
+            start = time.time()
+            total_loss_epoch = 0.0
+            it = enumerate(loader)
+            bar = tqdm(it, disable=verbose != 1) if tqdm is not None else None
+            try:
+                for _, (xb, yb) in (bar if bar is not None else it):
+                    if dp is not None:
+                        xb, yb = dp.shard(xb), dp.shard(yb)
+                    xd = xb.to(self.device).float()
+                    yd = yb.to(self.device).float()
+                    y_pred = model(xd).squeeze()
+                    optim.zero_grad()
+                    if isinstance(loss_func, list):
+                        assert len(loss_func) == self.num_tasks, \
+                            "the length of `loss_func` should be equal with `self.num_tasks`"
+                        loss = sum(loss_func[i](y_pred[:, i], yd[:, i], reduction='sum')
+                                   for i in range(self.num_tasks))
+                    else:
+                        loss = loss_func(y_pred, yd.squeeze(), reduction='sum')
+                    reg_loss = self.get_regularization_loss()
+                    if dp is None:
+                        total_loss = loss + reg_loss + self.aux_loss
+                        total_loss_epoch += total_loss.item()
+                        total_loss.backward()
+                    else:
+                        # data-loss gradients are SUMMED over ranks (the loss is a sum over the global
+                        # batch); the L2 term is identical on every replica and is added once, locally.
+                        loss.backward()
+                        dp.reduce_dense_grads(self)
+                        (reg_loss + self.aux_loss).backward()
+                        total_loss_epoch += dp.sum_scalar(loss.detach()) + (reg_loss + self.aux_loss).item()
+                    optim.step()
+                    if verbose > 0:
+                        yt, yp = yd, y_pred
+                        if dp is not None:
+                            yt, yp = dp.gather_rows(yd.reshape(-1)), dp.gather_rows(y_pred.detach().reshape(-1))
+                        for name, fn in self.metrics.items():
+                            train_result.setdefault(name, []).append(
+                                fn(yt.cpu().data.numpy(), yp.cpu().data.numpy().astype("float64")))
+            except KeyboardInterrupt:
+                if bar is not None:
+                    bar.close()
+                raise
+            if bar is not None:
+                bar.close()
+            epoch_logs["loss"] = total_loss_epoch / sample_num
+            for name, vals in train_result.items():
+                epoch_logs[name] = np.sum(vals) / steps_per_epoch
+            if do_validation:
+                for name, val in self.evaluate(val_x, val_y, batch_size).items():
+                    epoch_logs["val_" + name] = val
+            if verbose > 0 and (dp is None or dp.rank == 0):
+                msg = "{0}s - loss: {1: .4f}".format(int(time.time() - start), epoch_logs["loss"])
+                for name in self.metrics:
+                    msg += " - " + name + ": {0: .4f}".format(epoch_logs[name])
+                if do_validation:
+                    for name in self.metrics:
+                        msg += " - val_" + name + ": {0: .4f}".format(epoch_logs["val_" + name])
+                print('Epoch {0}/{1}'.format(epoch + 1, epochs))
+                print(msg)
+            if dp is None or dp.rank == 0:
+                cbs.on_epoch_end(epoch, epoch_logs)
+            else:
+                self.history.on_epoch_end(epoch, epoch_logs)
+            if dp is not None:
+                self.stop_training = dp.any_flag(self.stop_training)
+            if self.stop_training:
+                break
+        cbs.on_train_end()
+        return self.history
+
+    def evaluate(self, x, y, batch_size=256):
+        pred = self.predict(x, batch_size)
+        return {name: fn(y, pred) for name, fn in self.metrics.items()}
+
+    def predict(self, x, batch_size=256):
+        """float64 [N, 1] predictions (basemodel.py:325-352)."""
+        model = self.eval()
+        data = Data.TensorDataset(torch.from_numpy(self._as_matrix(x)))
+        loader = DataLoader(dataset=data, shuffle=False, batch_size=batch_size)
+        chunks = []
+        with torch.no_grad():
+            for (xb,) in loader:
+                chunks.append(model(xb.to(self.device).float()))
+        if not chunks:
+            return np.zeros((0, 1), dtype="float64")
+        return torch.cat(chunks).cpu().data.numpy().astype("float64")
+
+
+# ------------------------------------------------------------------------------------------------- #
+class _XDeepFMBase(BaseModel):
+    """Shared wiring of the three variants (deepctr/models/xdeepfm.py:42-107)."""
+
+    def _build_dnn(self, dnn_feature_columns, dnn_hidden_units, dnn_activation, l2_reg_dnn, dnn_dropout, dnn_use_bn,
+                   init_std, device):
+        self.dnn_hidden_units = dnn_hidden_units
+        self.use_dnn = len(dnn_feature_columns) > 0 and len(dnn_hidden_units) > 0
+        if self.use_dnn:
+            self.dnn = DNN(self.compute_input_dim(dnn_feature_columns), dnn_hidden_units, activation=dnn_activation,
+                           l2_reg=l2_reg_dnn, dropout_rate=dnn_dropout, use_bn=dnn_use_bn, init_std=init_std,
+                           device=device)
+            self.dnn_linear = nn.Linear(dnn_hidden_units[-1], 1, bias=False).to(device)
+            self.add_regularization_weight(
+                filter(lambda x: 'weight' in x[0] and 'bn' not in x[0], self.dnn.named_parameters()), l2=l2_reg_dnn)
+            self.add_regularization_weight(self.dnn_linear.weight, l2=l2_reg_dnn)
+
+    def _finish_cin(self, cin_out_dim, l2_reg_cin, device):
+        self.cin_linear = nn.Linear(cin_out_dim, 1, bias=False).to(device)
+        self.add_regularization_weight(filter(lambda x: 'weight' in x[0], self.cin.named_parameters()), l2=l2_reg_cin)
+
+    def forward(self, X):
+        emb_fm, dnn_in, logit = self.fused_inputs(X)
+        B = X.shape[0]
+        if self.use_cin:
+            cin_out = self.cin.forward_fm(emb_fm, B, self._plan.D)
+            logit = logit + self.cin_linear(cin_out)
+        if self.use_dnn:
+            logit = logit + self.dnn_linear(self.dnn(dnn_in))
+        return self.out(logit)
+
+
+class xDeepFM(_XDeepFMBase):
+    """xDeepFM (deepctr/models/xdeepfm.py:17-107)."""
+
+    def __init__(self, linear_feature_columns, dnn_feature_columns, dnn_hidden_units=(256, 256),
+                 cin_layer_size=(256, 128,), cin_split_half=True, cin_activation='relu', l2_reg_linear=0.00001,
+                 l2_reg_embedding=0.00001, l2_reg_dnn=0, l2_reg_cin=0, init_std=0.0001, seed=1024, dnn_dropout=0,
+                 dnn_activation='relu', dnn_use_bn=False, task='binary', device='cpu', gpus=None):
+        super().__init__(linear_feature_columns, dnn_feature_columns, l2_reg_linear=l2_reg_linear,
+                         l2_reg_embedding=l2_reg_embedding, init_std=init_std, seed=seed, task=task, device=device,
+                         gpus=gpus)
+        self._build_dnn(dnn_feature_columns, dnn_hidden_units, dnn_activation, l2_reg_dnn, dnn_dropout, dnn_use_bn,
+                        init_std, device)
+        self.cin_layer_size = cin_layer_size
+        self.use_cin = len(cin_layer_size) > 0 and len(dnn_feature_columns) > 0
+        if self.use_cin:
+            self.featuremap_num = (sum(cin_layer_size[:-1]) // 2 + cin_layer_size[-1]) if cin_split_half \
+                else sum(cin_layer_size)
+            self.cin = CIN(len(self.embedding_dict), cin_layer_size, cin_activation, cin_split_half, l2_reg_cin, seed,
+                           device=device)
+            self._finish_cin(self.featuremap_num, l2_reg_cin, device)
+        self.to(device)
+
+
+class xDeepFMAttention(_XDeepFMBase):
+    """xDeepFM whose CIN ends in attention pooling (deepctr/models/xdeepfm_attn.py:25-173)."""
+
+    def __init__(self, linear_feature_columns, dnn_feature_columns, dnn_hidden_units=(256, 256),
+                 cin_layer_size=(256, 128,), cin_split_half=True, cin_activation='relu', cin_num_heads=4,
+                 cin_attn_dropout=0.0, cin_use_layer_norm=True, cin_use_residual=True, l2_reg_linear=0.00001,
+                 l2_reg_embedding=0.00001, l2_reg_dnn=0, l2_reg_cin=0, init_std=0.0001, seed=1024, dnn_dropout=0,
+                 dnn_activation='relu', dnn_use_bn=False, task='binary', device='cpu', gpus=None):
+        super().__init__(linear_feature_columns, dnn_feature_columns, l2_reg_linear=l2_reg_linear,
+                         l2_reg_embedding=l2_reg_embedding, init_std=init_std, seed=seed, task=task, device=device,
+                         gpus=gpus)
+        self._build_dnn(dnn_feature_columns, dnn_hidden_units, dnn_activation, l2_reg_dnn, dnn_dropout, dnn_use_bn,
+                        init_std, device)
+        self.cin_layer_size = cin_layer_size
+        self.use_cin = len(cin_layer_size) > 0 and len(dnn_feature_columns) > 0
+        if self.use_cin:
+            emb = next(fc.embedding_dim for fc in dnn_feature_columns if isinstance(fc, SparseFeat))
+            self.featuremap_num = (sum(cin_layer_size[:-1]) // 2 + cin_layer_size[-1]) if cin_split_half \
+                else sum(cin_layer_size)
+            self.cin = CINAttention(field_size=len(self.embedding_dict), embedding_size=emb,
+                                    layer_size=cin_layer_size, activation=cin_activation, split_half=cin_split_half,
+                                    num_heads=cin_num_heads, attn_dropout=cin_attn_dropout,
+                                    use_layer_norm=cin_use_layer_norm, use_residual=cin_use_residual,
+                                    l2_reg=l2_reg_cin, seed=seed, device=device)
+            self._finish_cin(self.featuremap_num, l2_reg_cin, device)
+        self.to(device)
+
+
+class xDeepFMAttentionV2(_XDeepFMBase):
+    """Variant without the output projection: the CIN block returns [B, D]
+    (deepctr/models/xdeepfm_attn.py:176-301)."""
+
+    def __init__(self, linear_feature_columns, dnn_feature_columns, dnn_hidden_units=(256, 256),
+                 cin_layer_size=(256, 128,), cin_split_half=True, cin_activation='relu', cin_num_heads=4,
+                 cin_attn_dropout=0.0, cin_use_layer_norm=True, cin_use_residual=True, cin_num_attn_layers=1,
+                 l2_reg_linear=0.00001, l2_reg_embedding=0.00001, l2_reg_dnn=0, l2_reg_cin=0, init_std=0.0001,
+                 seed=1024, dnn_dropout=0, dnn_activation='relu', dnn_use_bn=False, task='binary', device='cpu',
+                 gpus=None):
+        super().__init__(linear_feature_columns, dnn_feature_columns, l2_reg_linear=l2_reg_linear,
+                         l2_reg_embedding=l2_reg_embedding, init_std=init_std, seed=seed, task=task, device=device,
+                         gpus=gpus)
+        self._build_dnn(dnn_feature_columns, dnn_hidden_units, dnn_activation, l2_reg_dnn, dnn_dropout, dnn_use_bn,
+                        init_std, device)
+        self.cin_layer_size = cin_layer_size
+        self.use_cin = len(cin_layer_size) > 0 and len(dnn_feature_columns) > 0
+        if self.use_cin:
+            emb = next(fc.embedding_dim for fc in dnn_feature_columns if isinstance(fc, SparseFeat))
+            self.cin = CINAttentionV2(field_size=len(self.embedding_dict), embedding_size=emb,
+                                      layer_size=cin_layer_size, activation=cin_activation,
+                                      split_half=cin_split_half, num_heads=cin_num_heads,
+                                      attn_dropout=cin_attn_dropout, use_layer_norm=cin_use_layer_norm,
+                                      use_residual=cin_use_residual, num_attn_layers=cin_num_attn_layers,
+                                      l2_reg=l2_reg_cin, seed=seed, device=device)
+            self._finish_cin(emb, l2_reg_cin, device)
+        self.to(device)

@@ -1,0 +1,278 @@
+"""torch.autograd wrappers around the C ABI of libxdfm_hip.so.
+
+PyTorch is plumbing here (device memory, the current HIP stream, the autograd tape); every
+arithmetic step of the embedding gather and of the CIN stack runs in the hand-written kernels.
+All ops require float32 CUDA (ROCm) tensors and raise otherwise -- there is no CPU path.
+"""
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+ACT_CODES = {"linear": 0, "relu": 1}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_cuda(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "xdfm: %s is on %s -- the xDeepFM hot path only runs on an MI355X through libxdfm_hip.so; "
+            "there is no CPU fallback (the CPU restatement lives in oracle/ and is test-only)." % (name, t.device))
+    if t.dtype != torch.float32:
+        raise TypeError("xdfm: %s must be float32, got %s" % (name, t.dtype))
+
+
+def activation_code(name) -> int:
+    key = name.lower() if isinstance(name, str) else name
+    if key not in ACT_CODES:
+        raise NotImplementedError("xdfm CIN kernels implement activation 'relu' and 'linear', got %r" % (name,))
+    return ACT_CODES[key]
+
+
+# --------------------------------------------------------------------------------------------- #
+# embedding gather                                                                               #
+# --------------------------------------------------------------------------------------------- #
+class EmbedPlan:
+    """Device-side metadata of one gather: which column of X feeds which table."""
+
+    def __init__(self, sparse_cols: Sequence[int], vocab: Sequence[int], dense_cols: Sequence[int], emb_dim: int):
+        self.m = len(sparse_cols)
+        self.nd = len(dense_cols)
+        self.D = int(emb_dim)
+        self.sparse_cols = [int(c) for c in sparse_cols]
+        self.vocab = [int(v) for v in vocab]
+        self.dense_cols = [int(c) for c in dense_cols]
+        self._dev = {}
+        self._ptr_cache = {}
+        self.dp = None            # set by xdfm_amd.dist to exchange row gradients across ranks
+
+    def on(self, device):
+        key = str(device)
+        if key not in self._dev:
+            i32 = dict(dtype=torch.int32, device=device)
+            self._dev[key] = (torch.tensor(self.sparse_cols, **i32), torch.tensor(self.vocab, **i32),
+                              torch.tensor(self.dense_cols if self.nd else [0], **i32),
+                              torch.zeros(1, **i32))
+        return self._dev[key]
+
+    def pointer_table(self, tensors: Sequence[torch.Tensor], tag: str):
+        """int64 device array of base pointers (re-uploaded only when a pointer changed)."""
+        ptrs = tuple(t.data_ptr() for t in tensors)
+        hit = self._ptr_cache.get(tag)
+        if hit is None or hit[0] != ptrs:
+            hit = (ptrs, torch.tensor(ptrs, dtype=torch.int64, device=tensors[0].device))
+            self._ptr_cache[tag] = hit
+        return hit[1]
+
+    def check_ids(self, device) -> bool:
+        """True when a gather since the last call saw an id outside [0, vocab) (syncs the stream)."""
+        flag = self.on(device)[3]
+        bad = bool(flag.item())
+        flag.zero_()
+        return bad
+
+
+class EmbedGather(torch.autograd.Function):
+    """X [B, cols] -> (emb_fm [m, B*D], dnn_in [B, m*D+nd], lin [B, 1]).
+
+    replaces deepctr/models/basemodel.py:354-380 + :63-92 + deepctr/inputs.py:126-132."""
+
+    @staticmethod
+    def forward(ctx, X, dense_w, plan: EmbedPlan, has_lin: bool, *tables):
+        _need_cuda(X, "X")
+        lib = _lib.load()
+        m, D, nd = plan.m, plan.D, plan.nd
+        emb_tables = tables[:m]
+        lin_tables = tables[m:2 * m] if has_lin else ()
+        for t in tables:
+            _need_cuda(t, "embedding table")
+            if not t.is_contiguous():
+                raise ValueError("xdfm: embedding tables must be contiguous")
+        X = X.contiguous()
+        B = X.shape[0]
+        cols, vocab, dcols, flag = plan.on(X.device)
+        emb_fm = torch.empty((m, B * D), dtype=torch.float32, device=X.device)
+        dnn_in = torch.empty((B, m * D + nd), dtype=torch.float32, device=X.device)
+        lin = torch.empty((B, 1), dtype=torch.float32, device=X.device)
+        tp = plan.pointer_table(emb_tables, "emb")
+        lp = plan.pointer_table(lin_tables, "lin") if has_lin else None
+        dw = dense_w.contiguous() if (dense_w is not None and nd > 0) else None
+        _lib.check(lib.xdfm_embed_gather_fwd(_ptr(X), X.stride(0), B, _ptr(tp), _ptr(lp), _ptr(cols), _ptr(vocab),
+                                             m, D, _ptr(dcols) if nd else None, _ptr(dw), nd, _ptr(emb_fm),
+                                             _ptr(dnn_in), _ptr(lin), _ptr(flag), _stream()), "embed_gather_fwd")
+        ctx.plan, ctx.has_lin = plan, has_lin
+        ctx.shapes = [tuple(t.shape) for t in tables]
+        ctx.save_for_backward(X)
+        return emb_fm, dnn_in, lin
+
+    @staticmethod
+    def backward(ctx, d_emb, d_dnn, d_lin):
+        (X,) = ctx.saved_tensors
+        plan, has_lin = ctx.plan, ctx.has_lin
+        lib = _lib.load()
+        m, D, nd = plan.m, plan.D, plan.nd
+        dev = X.device
+        sizes = [s[0] * s[1] for s in ctx.shapes]
+        flat = torch.zeros(sum(sizes) + max(nd, 1), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for s, n in zip(ctx.shapes, sizes):
+            grads.append(flat[off:off + n].view(s))
+            off += n
+        d_w = flat[off:off + nd].view(nd, 1) if nd else None
+        cols, vocab, dcols, _ = plan.on(dev)
+        gp = torch.tensor([g.data_ptr() for g in grads[:m]], dtype=torch.int64, device=dev)
+        lp = torch.tensor([g.data_ptr() for g in grads[m:2 * m]], dtype=torch.int64, device=dev) if has_lin else None
+        pieces = [(X, d_emb, d_dnn, d_lin)]
+        if plan.dp is not None:
+            pieces = plan.dp.exchange_rows(X, d_emb, d_dnn, d_lin)
+        for (Xr, de, dd, dl) in pieces:
+            B = Xr.shape[0]
+            de = de.contiguous() if de is not None else None
+            dd = dd.contiguous() if dd is not None else None
+            dl = dl.contiguous() if dl is not None else None
+            _lib.check(lib.xdfm_embed_scatter_bwd(_ptr(Xr), Xr.stride(0), B, _ptr(cols), _ptr(vocab), m, D,
+                                                  _ptr(dcols) if nd else None, nd, _ptr(de), _ptr(dd), _ptr(dl),
+                                                  _ptr(gp), _ptr(lp), _ptr(d_w), _stream()), "embed_scatter_bwd")
+        need_w = ctx.needs_input_grad[1]
+        return (None, d_w if (need_w and nd) else None, None, None) + tuple(grads)
+
+
+# --------------------------------------------------------------------------------------------- #
+# CIN stack                                                                                      #
+# --------------------------------------------------------------------------------------------- #
+def cin_geometry(m: int, layer_size: Sequence[int], split_half: bool):
+    """Per level: (H, Hp, hid_rows, dir0, dir_rows, dir_off).  Mirrors field_nums of
+    deepctr/layers/interaction.py:183-201 and the split of :231-240."""
+    levels, Hp, off = [], m, 0
+    L = len(layer_size)
+    for i, H in enumerate(layer_size):
+        if split_half:
+            if i != L - 1:
+                hid, dir0, drows = H // 2, H // 2, H - H // 2
+            else:
+                hid, dir0, drows = 0, 0, H
+        else:
+            hid, dir0, drows = H, 0, H
+        levels.append((H, Hp, hid, dir0, drows, off))
+        off += drows
+        Hp = hid
+    return levels, off
+
+
+class CINStack(torch.autograd.Function):
+    """All CIN levels.  x0 is FM layout [m, B*D].
+
+    pool == "sum": returns [B, featuremap_num]   (deepctr/layers/interaction.py:207-248)
+    pool == "fm" : returns the direct-connect feature maps, FM layout [featuremap_num, B*D]
+                   (the tensor deepctr/layers/cin_attention.py:292 feeds to the attention block).
+    """
+
+    @staticmethod
+    def forward(ctx, x0, B, D, layer_size, split_half, act, pool, *params):
+        _need_cuda(x0, "cin input")
+        lib = _lib.load()
+        m = x0.shape[0]
+        N = B * D
+        assert x0.shape[1] == N and x0.is_contiguous()
+        levels, fm = cin_geometry(m, layer_size, split_half)
+        dev = x0.device
+        outs: List[torch.Tensor] = []
+        xp = x0
+        result = torch.empty((B, fm), dtype=torch.float32, device=dev) if pool == "sum" else None
+        for l, (H, Hp, hid, dir0, drows, off) in enumerate(levels):
+            W, bias = params[2 * l], params[2 * l + 1]
+            _need_cuda(W, "cin weight")
+            W2 = W.reshape(H, Hp * m).contiguous()
+            wf = torch.empty(lib.xdfm_cin_fwd_pack_elems(H, Hp, m), dtype=torch.float32, device=dev)
+            _lib.check(lib.xdfm_cin_fwd_pack(_ptr(W2), H, Hp, m, _ptr(wf), _stream()), "cin_fwd_pack")
+            A = torch.empty((H, N), dtype=torch.float32, device=dev)
+            _lib.check(lib.xdfm_cin_level_fwd(_ptr(xp), _ptr(x0), _ptr(wf), _ptr(bias.contiguous()), H, Hp, m, N, act,
+                                              _ptr(A), _stream()), "cin_level_fwd")
+            if pool == "sum":
+                _lib.check(lib.xdfm_cin_direct_sum(_ptr(A), dir0, drows, B, D, _ptr(result), fm, off, _stream()),
+                           "cin_direct_sum")
+            outs.append(A)
+            xp = A[:hid] if hid > 0 else None
+        ctx.cfg = (B, D, tuple(layer_size), split_half, act, pool, m)
+        ctx.save_for_backward(x0, *outs, *params)
+        if pool == "sum":
+            return result
+        return torch.cat([A[dir0:dir0 + drows] for A, (H, Hp, hid, dir0, drows, off) in zip(outs, levels)], dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        B, D, layer_size, split_half, act, pool, m = ctx.cfg
+        L = len(layer_size)
+        saved = ctx.saved_tensors
+        x0, outs, params = saved[0], saved[1:1 + L], saved[1 + L:]
+        N = B * D
+        dev = x0.device
+        levels, fm = cin_geometry(m, layer_size, split_half)
+        g = g.contiguous()
+        dx0 = torch.zeros((m, N), dtype=torch.float32, device=dev)
+        grads = [None] * (2 * L)
+        dhid = None                                  # gradient w.r.t. this level's hidden rows
+        for l in range(L - 1, -1, -1):
+            H, Hp, hid, dir0, drows, off = levels[l]
+            A = outs[l]
+            xp = x0 if l == 0 else outs[l - 1][:levels[l - 1][2]]
+            W, bias = params[2 * l], params[2 * l + 1]
+            dOut = torch.empty((H, N), dtype=torch.float32, device=dev)
+            dbias = torch.zeros((H,), dtype=torch.float32, device=dev)
+            has_hid = dhid is not None and hid > 0
+            _lib.check(lib.xdfm_cin_dout(_ptr(A), H, B, D, act, _ptr(dhid) if has_hid else None, 0,
+                                         hid if has_hid else 0, _ptr(g), 0 if pool == "sum" else 1,
+                                         fm if pool == "sum" else N, off, dir0, drows, _ptr(dOut), _ptr(dbias),
+                                         _stream()), "cin_dout")
+            if ctx.needs_input_grad[7 + 2 * l]:
+                ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m), dtype=torch.float32, device=dev)
+                dW = torch.empty((H, Hp * m), dtype=torch.float32, device=dev)
+                _lib.check(lib.xdfm_cin_level_bwd_w(_ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW),
+                                                    _stream()), "cin_level_bwd_w")
+                grads[2 * l] = dW.view(W.shape)
+            if ctx.needs_input_grad[8 + 2 * l]:
+                grads[2 * l + 1] = dbias
+            # dX: H <= 256 rows of the contraction per launch
+            dxp = torch.zeros((Hp, N), dtype=torch.float32, device=dev)
+            W2 = W.reshape(H, Hp * m)
+            for h0 in range(0, H, 256):
+                hc = min(256, H - h0)
+                wz = torch.empty(lib.xdfm_cin_bwd_pack_elems(hc, Hp, m), dtype=torch.float32, device=dev)
+                _lib.check(lib.xdfm_cin_bwd_pack(_ptr(W2[h0:h0 + hc].contiguous()), hc, Hp, m, _ptr(wz), _stream()),
+                           "cin_bwd_pack")
+                _lib.check(lib.xdfm_cin_level_bwd_x(_ptr(dOut[h0:h0 + hc]), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m,
+                                                    N, _ptr(dxp), _ptr(dx0), _stream()), "cin_level_bwd_x")
+            if l == 0:
+                dx0 += dxp                               # x_prev of level 0 is x0 itself
+            dhid = dxp
+        return (dx0, None, None, None, None, None, None) + tuple(grads)
+
+
+def cin_stack(x0_fm, B, D, layer_size, split_half, activation, pool, weights, biases):
+    act = activation_code(activation)
+    params = []
+    for w, b in zip(weights, biases):
+        params += [w, b]
+    return CINStack.apply(x0_fm, B, D, tuple(layer_size), bool(split_half), act, pool, *params)
+
+
+def to_fm_layout(x: torch.Tensor) -> torch.Tensor:
+    """[B, R, D] -> FM layout [R, B*D] (a transpose; used when a caller hands the reference layout)."""
+    B, R, D = x.shape
+    return x.permute(1, 0, 2).reshape(R, B * D).contiguous()
+
+
+def from_fm_layout(t: torch.Tensor, B: int, D: int) -> torch.Tensor:
+    """FM layout [R, B*D] -> [B, R, D]."""
+    R = t.shape[0]
+    return t.view(R, B, D).permute(1, 0, 2)
