@@ -57,15 +57,19 @@ class Linear(nn.Module):
         self.sparse_feature_columns, self.dense_feature_columns, self.varlen_sparse_feature_columns = \
             split_columns(feature_columns)
         _reject_varlen(self.varlen_sparse_feature_columns)
+        # All draws happen on the CPU generator and the module moves afterwards, so a seed gives the
+        # same initial weights on every device (= the reference's CPU path; on a CUDA device the
+        # reference itself would take these two draws from the device generator, basemodel.py:47-61).
         self.embedding_dict = create_embedding_matrix(feature_columns, init_std, linear=True, sparse=False,
-                                                      device=device)
+                                                      device='cpu')
         for emb in self.embedding_dict.values():          # second draw, basemodel.py:55-56
             nn.init.normal_(emb.weight, mean=0, std=init_std)
         n_dense = sum(fc.dimension for fc in self.dense_feature_columns)
         if n_dense > 0:
-            self.weight = nn.Parameter(torch.Tensor(n_dense, 1).to(device))
+            self.weight = nn.Parameter(torch.Tensor(n_dense, 1))
             nn.init.normal_(self.weight, mean=0, std=init_std)
         self._plan = None
+        self.to(device)
 
     def tables(self):
         return [self.embedding_dict[fc.embedding_name].weight for fc in self.sparse_feature_columns]
