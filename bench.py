@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Headline benchmark: xDeepFM training throughput (examples/sec) on BASELINE.json config 2
+-- Criteo-1TB shape (26 sparse + 13 dense fields), per-GPU batch 4096, emb_dim 16,
+cin_layer_size (256,128,128), dnn (256,256), fp32, synthetic data, random-init weights.
+
+A "step" is one pass of the hot path over one resident batch, exactly the per-batch sequence of
+the reference's fit loop (deepctr/models/basemodel.py:245-262): forward -> BCE(sum) -> L2 term ->
+backward -> Adam step.  Inputs are in HBM before the timed region starts.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant hand-written kernel (by summed
+device time inside the timed region, HIP events on the launch stream); `cpu_baseline` is the CPU
+oracle (a port of the reference's op sequence) timed on this host's cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "xdeepfm-pytorch_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "criteo_c2": dict(n_sparse=26, n_dense=13, emb_dim=16, cin=(256, 128, 128), dnn=(256, 256), batch=4096),
+    # BASELINE.json configs[0] (CPU plumbing shape), handy for quick runs
+    "criteo_c1": dict(n_sparse=26, n_dense=13, emb_dim=8, cin=(128, 128), dnn=(256, 256), batch=4096),
+}
+
+
+def synthetic_batches(n_batches, batch, vocab, n_dense, seed):
+    """Criteo-shaped batches: Zipf-like ids floor(V*u^3), dense ~ U(0,1), y ~ Bern(0.25)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_batches):
+        ids = np.floor(np.asarray(vocab)[None, :] * rng.random((batch, len(vocab))) ** 3)
+        ids = np.minimum(ids, np.asarray(vocab)[None, :] - 1)
+        dense = rng.random((batch, n_dense))
+        X = np.concatenate([ids, dense], axis=1).astype(np.float32)
+        y = (rng.random((batch, 1)) < 0.25).astype(np.float32)
+        out.append((X, y))
+    return out
+
+
+def build_model(cfg, vocab_size, device):
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    cols = [SparseFeat("C%d" % (i + 1), vocab_size, cfg["emb_dim"]) for i in range(cfg["n_sparse"])]
+    cols += [DenseFeat("I%d" % (i + 1), 1) for i in range(cfg["n_dense"])]
+    model = xDeepFM(cols, cols, dnn_hidden_units=cfg["dnn"], cin_layer_size=cfg["cin"], l2_reg_dnn=1e-5,
+                    device=device)
+    model.compile("adam", "binary_crossentropy", metrics=[])
+    return model
+
+
+def train_step(model, xb, yb, dp):
+    """basemodel.py:245-262 without the two .item() host syncs (losses stay on the device)."""
+    y_pred = model(xb).squeeze()
+    model.optim.zero_grad()
+    loss = torch.nn.functional.binary_cross_entropy(y_pred, yb.squeeze(), reduction="sum")
+    reg = model.get_regularization_loss()
+    if dp is None:
+        (loss + reg + model.aux_loss).backward()
+    else:
+        loss.backward()
+        dp.reduce_dense_grads(model)
+        (reg + model.aux_loss).backward()
+    model.optim.step()
+    return loss
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return min(n, 64)
+
+
+def log(msg):
+    print("[bench %7.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def cpu_baseline(cfg, vocab_size, rows, steps):
+    """The CPU oracle (torch-CPU port of the reference's op sequence) on `rows` rows of the same
+    workload: 1 warm-up + up to `steps` timed train steps (stops after ~25 s) on the usable cores."""
+    from oracle import xdeepfm_oracle as orc
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    names = ["C%d" % (i + 1) for i in range(cfg["n_sparse"])]
+    dnames = ["I%d" % (i + 1) for i in range(cfg["n_dense"])]
+    spec = orc.Spec(names, [vocab_size] * cfg["n_sparse"], dnames, cfg["emb_dim"], tuple(cfg["cin"]), True, "relu",
+                    tuple(cfg["dnn"]), l2_reg_dnn=1e-5)
+    state = orc.init_state(spec)
+    batches = [(torch.from_numpy(X), torch.from_numpy(y)) for X, y in
+               synthetic_batches(steps + 1, rows, [vocab_size] * cfg["n_sparse"], cfg["n_dense"], seed=7)]
+    params = [p.requires_grad_(True) for p in state.values()]
+    opt = torch.optim.Adam(params)
+
+    def step(X, y):
+        tot, _, _ = orc.total_loss(X, y, state, spec)
+        opt.zero_grad()
+        tot.backward()
+        opt.step()
+    step(*batches[0])
+    log("cpu baseline warm-up step done (%d threads)" % threads)
+    t0 = time.perf_counter()
+    done = 0
+    for X, y in batches[1:]:
+        step(X, y)
+        done += 1
+        if time.perf_counter() - t0 > 25.0:
+            break
+    dt = time.perf_counter() - t0
+    steps = done
+    return dict(value=rows * steps / dt, unit="examples/sec", cores=threads, kind="port",
+                sample="%d train steps of %d rows (same model/config, fp32, torch-CPU oracle), %.2f s/step"
+                       % (steps, rows, dt / steps))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="criteo_c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--vocab", type=int, default=100000, help="rows per embedding table (SURVEY 8d 'mid' preset)")
+    ap.add_argument("--cpu-rows", type=int, default=1024)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--option", action="append", default=[], help="libxdfm tuning knob key=value")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
+                  % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from xdfm_amd import _lib, ops
+    from xdfm_amd import dist as xdist
+    for kv in args.option:
+        k, v = kv.split("=")
+        _lib.set_option(k, int(v))
+    cfg = WORKLOADS[args.workload]
+    B = cfg["batch"]
+    log("building model")
+    model = build_model(cfg, args.vocab, device)
+    model.train()
+    dp = xdist.current()
+    # every rank draws its own resident shard of the global batch (weak scaling: B rows per GPU)
+    n_res = 8
+    batches = [(torch.from_numpy(X).to(device), torch.from_numpy(y).to(device)) for X, y in
+               synthetic_batches(n_res, B, [args.vocab] * cfg["n_sparse"], cfg["n_dense"], seed=2025 + rank)]
+    if dp is not None:
+        dp._n_global = B * world          # the scatter exchange needs the global split (equal shards)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("warm-up")
+    for s in range(args.warmup):
+        train_step(model, *batches[s % n_res], dp)
+    barrier()
+    log("timed region")
+    ops.PROFILE = []                       # (name, flops, start_event, end_event) per heavy launch
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        loss = train_step(model, *batches[s % n_res], dp)
+    barrier()
+    dt = time.perf_counter() - t0
+    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not np.isfinite(float(loss.item())):
+        raise RuntimeError("non-finite loss in the benchmark loop")
+
+    if rank == 0:
+        per_kernel = {}
+        for name, work, e0, e1 in prof:
+            acc = per_kernel.setdefault(name, [0.0, 0.0, 0])
+            acc[0] += e0.elapsed_time(e1) * 1e-3
+            acc[1] += work
+            acc[2] += 1
+        mfma = {k: v for k, v in per_kernel.items() if not k.endswith("[bytes]")}
+        roof = None
+        if mfma:
+            name, (secs, flops, n) = max(mfma.items(), key=lambda kv: kv[1][0])
+            achieved = flops / secs / 1e12
+            roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
+                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        launches=n, avg_ms=round(secs / n * 1e3, 4))
+        kernels = {}
+        for k, v in sorted(per_kernel.items()):
+            rate = v[1] / v[0] if v[0] > 0 else 0.0
+            kernels[k.replace("[bytes]", "")] = dict(
+                ms_per_step=round(v[0] / args.steps * 1e3, 4),
+                **({"GBps": round(rate / 1e9, 1), "frac_hbm": round(rate / 1e9 / HBM_PEAK_GBS, 4)}
+                   if k.endswith("[bytes]") else {"TFLOPs": round(rate / 1e12, 2)}))
+        out = {
+            "metric": "examples/sec (xDeepFM train step, Criteo-shape synthetic, bs=4096 per GPU)",
+            "value": round(B * world * args.steps / dt, 1),
+            "unit": "examples/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d sparse + %d dense, emb_dim %d, cin %s, dnn %s, vocab %d/field, "
+                                   "per-GPU batch %d, Adam + L2, fp32" % (
+                                       args.workload, cfg["n_sparse"], cfg["n_dense"], cfg["emb_dim"],
+                                       list(cfg["cin"]), list(cfg["dnn"]), args.vocab, B),
+                       "global_batch": B * world, "parallelism": "dp%d" % world},
+            "roofline": roof,
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.vocab, args.cpu_rows, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

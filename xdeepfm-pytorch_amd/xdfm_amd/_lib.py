@@ -7,6 +7,11 @@ import ctypes
 import os
 from ctypes import c_char_p, c_int, c_long, c_size_t, c_void_p
 
+# torch must be imported BEFORE the library is dlopen'ed: the torch wheel bundles its own
+# libamdhip64 and the process must end up with ONE HIP runtime (the one that owns torch's device
+# context and streams).  Loaded first, torch's copy satisfies our DT_NEEDED by soname.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XDFM_LIB", os.path.join(_HERE, "libxdfm_hip.so"))
 

@@ -13,6 +13,21 @@ from . import _lib
 
 ACT_CODES = {"linear": 0, "relu": 1}
 
+# bench.py sets this to a list to collect (name, algorithmic work, start event, end event) for each
+# heavy launch; the events are recorded on torch's current stream, the one the kernels run on.
+PROFILE = None
+
+
+def _run(name, work, fn):
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    PROFILE.append((name, work, e0, e1))
+    return rc
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -106,9 +121,12 @@ class EmbedGather(torch.autograd.Function):
         tp = plan.pointer_table(emb_tables, "emb")
         lp = plan.pointer_table(lin_tables, "lin") if has_lin else None
         dw = dense_w.contiguous() if (dense_w is not None and nd > 0) else None
-        _lib.check(lib.xdfm_embed_gather_fwd(_ptr(X), X.stride(0), B, _ptr(tp), _ptr(lp), _ptr(cols), _ptr(vocab),
-                                             m, D, _ptr(dcols) if nd else None, _ptr(dw), nd, _ptr(emb_fm),
-                                             _ptr(dnn_in), _ptr(lin), _ptr(flag), _stream()), "embed_gather_fwd")
+        # algorithmic bytes: X row + table rows (+ linear rows) + both outputs + logit
+        nbytes = B * (4 * (m + nd) + m * (4 * D + (4 if has_lin else 0)) + 4 * m * D + 4 * (m * D + nd) + 4)
+        _lib.check(_run("embed_gather_fwd[bytes]", nbytes, lambda: lib.xdfm_embed_gather_fwd(
+            _ptr(X), X.stride(0), B, _ptr(tp), _ptr(lp), _ptr(cols), _ptr(vocab), m, D,
+            _ptr(dcols) if nd else None, _ptr(dw), nd, _ptr(emb_fm), _ptr(dnn_in), _ptr(lin), _ptr(flag),
+            _stream())), "embed_gather_fwd")
         ctx.plan, ctx.has_lin = plan, has_lin
         ctx.shapes = [tuple(t.shape) for t in tables]
         ctx.save_for_backward(X)
@@ -139,9 +157,10 @@ class EmbedGather(torch.autograd.Function):
             de = de.contiguous() if de is not None else None
             dd = dd.contiguous() if dd is not None else None
             dl = dl.contiguous() if dl is not None else None
-            _lib.check(lib.xdfm_embed_scatter_bwd(_ptr(Xr), Xr.stride(0), B, _ptr(cols), _ptr(vocab), m, D,
-                                                  _ptr(dcols) if nd else None, nd, _ptr(de), _ptr(dd), _ptr(dl),
-                                                  _ptr(gp), _ptr(lp), _ptr(d_w), _stream()), "embed_scatter_bwd")
+            nbytes = B * (4 * (m + nd) + 2 * 4 * m * D + 4 + 4 * m * (D + 1))
+            _lib.check(_run("embed_scatter_bwd[bytes]", nbytes, lambda: lib.xdfm_embed_scatter_bwd(
+                _ptr(Xr), Xr.stride(0), B, _ptr(cols), _ptr(vocab), m, D, _ptr(dcols) if nd else None, nd,
+                _ptr(de), _ptr(dd), _ptr(dl), _ptr(gp), _ptr(lp), _ptr(d_w), _stream())), "embed_scatter_bwd")
         need_w = ctx.needs_input_grad[1]
         return (None, d_w if (need_w and nd) else None, None, None) + tuple(grads)
 
@@ -195,8 +214,9 @@ class CINStack(torch.autograd.Function):
             wf = torch.empty(lib.xdfm_cin_fwd_pack_elems(H, Hp, m), dtype=torch.float32, device=dev)
             _lib.check(lib.xdfm_cin_fwd_pack(_ptr(W2), H, Hp, m, _ptr(wf), _stream()), "cin_fwd_pack")
             A = torch.empty((H, N), dtype=torch.float32, device=dev)
-            _lib.check(lib.xdfm_cin_level_fwd(_ptr(xp), _ptr(x0), _ptr(wf), _ptr(bias.contiguous()), H, Hp, m, N, act,
-                                              _ptr(A), _stream()), "cin_level_fwd")
+            bias_c = bias.contiguous()
+            _lib.check(_run("cin_level_fwd", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_fwd(
+                _ptr(xp), _ptr(x0), _ptr(wf), _ptr(bias_c), H, Hp, m, N, act, _ptr(A), _stream())), "cin_level_fwd")
             if pool == "sum":
                 _lib.check(lib.xdfm_cin_direct_sum(_ptr(A), dir0, drows, B, D, _ptr(result), fm, off, _stream()),
                            "cin_direct_sum")
@@ -237,8 +257,8 @@ class CINStack(torch.autograd.Function):
             if ctx.needs_input_grad[7 + 2 * l]:
                 ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m), dtype=torch.float32, device=dev)
                 dW = torch.empty((H, Hp * m), dtype=torch.float32, device=dev)
-                _lib.check(lib.xdfm_cin_level_bwd_w(_ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW),
-                                                    _stream()), "cin_level_bwd_w")
+                _lib.check(_run("cin_level_bwd_w", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_w(
+                    _ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW), _stream())), "cin_level_bwd_w")
                 grads[2 * l] = dW.view(W.shape)
             if ctx.needs_input_grad[8 + 2 * l]:
                 grads[2 * l + 1] = dbias
@@ -248,10 +268,12 @@ class CINStack(torch.autograd.Function):
             for h0 in range(0, H, 256):
                 hc = min(256, H - h0)
                 wz = torch.empty(lib.xdfm_cin_bwd_pack_elems(hc, Hp, m), dtype=torch.float32, device=dev)
-                _lib.check(lib.xdfm_cin_bwd_pack(_ptr(W2[h0:h0 + hc].contiguous()), hc, Hp, m, _ptr(wz), _stream()),
-                           "cin_bwd_pack")
-                _lib.check(lib.xdfm_cin_level_bwd_x(_ptr(dOut[h0:h0 + hc]), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m,
-                                                    N, _ptr(dxp), _ptr(dx0), _stream()), "cin_level_bwd_x")
+                wc = W2[h0:h0 + hc].contiguous()
+                _lib.check(lib.xdfm_cin_bwd_pack(_ptr(wc), hc, Hp, m, _ptr(wz), _stream()), "cin_bwd_pack")
+                dOc = dOut[h0:h0 + hc]
+                _lib.check(_run("cin_level_bwd_x", 2.0 * hc * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_x(
+                    _ptr(dOc), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m, N, _ptr(dxp), _ptr(dx0), _stream())),
+                    "cin_level_bwd_x")
             if l == 0:
                 dx0 += dxp                               # x_prev of level 0 is x0 itself
             dhid = dxp
