@@ -128,6 +128,19 @@ size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m);
 int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
                          int H, int Hp, int m, long N, float* ws, float* dW, void* stream);
 
+/* ------------------------------------------------------------------ L2 regulariser (K6)
+ * replaces: deepctr/models/basemodel.py:412-428 (per-tensor square / mul / sum / add loop over
+ *           ~58 tensors, every embedding table in full) and its autograd.
+ * ptrs: device array of T tensor base pointers, numel: device long[T], coeff: device float[T]
+ * (the l2 strength of each tensor).  fwd: out[0] = sum_t coeff[t] * sum(w_t^2), deterministic;
+ * partials: scratch of 32*T floats.  bwd: g_t = 2*coeff[t]*gscale[0]*w_t written (accumulate=0) or
+ * added (accumulate=1) to the T buffers in gptrs; gscale is a device scalar.
+ */
+int xdfm_l2_reg_fwd(const float* const* ptrs, const long* numel, const float* coeff, int T,
+                    float* partials, float* out, void* stream);
+int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* coeff, int T,
+                    const float* gscale, float* const* gptrs, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

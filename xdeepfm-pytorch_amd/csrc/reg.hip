@@ -1,0 +1,97 @@
+// K6: multi-tensor L2 regulariser.
+//
+// replaces the Python loop of deepctr/models/basemodel.py:412-428, which issues square / mul /
+// sum / add per regularised tensor (~58 tensors incl. every embedding table in full: >200 launches
+// forward and more in backward) with one reduction launch + one gradient launch.
+//
+//   value  = sum_t coeff[t] * sum_i w_t[i]^2                (forward)
+//   g_t[i] = 2 * coeff[t] * gscale * w_t[i]                 (backward, gscale = d loss / d value)
+//
+// Deterministic: every tensor is reduced by a fixed grid of REG_BLOCKS blocks into partials that a
+// single block sums in a fixed order.
+#include "xdfm_internal.h"
+
+#define REG_BLOCKS 32
+#define REG_THREADS 256
+
+__global__ __launch_bounds__(REG_THREADS) void l2_sumsq_kernel(const float* const* __restrict__ ptrs,
+                                                               const long* __restrict__ numel,
+                                                               float* __restrict__ partials) {
+    const int t = blockIdx.y;
+    const float* __restrict__ w = ptrs[t];
+    const long n = numel[t];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const long stride = (long)REG_BLOCKS * REG_THREADS;
+    long i = (long)blockIdx.x * REG_THREADS + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const float v0 = w[i], v1 = w[i + stride], v2 = w[i + 2 * stride], v3 = w[i + 3 * stride];
+        a0 = fmaf(v0, v0, a0); a1 = fmaf(v1, v1, a1); a2 = fmaf(v2, v2, a2); a3 = fmaf(v3, v3, a3);
+    }
+    for (; i < n; i += stride) { const float v = w[i]; a0 = fmaf(v, v, a0); }
+    float part = (a0 + a1) + (a2 + a3);
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    __shared__ float wsum[REG_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[t * REG_BLOCKS + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(REG_THREADS) void l2_finish_kernel(const float* __restrict__ partials,
+                                                                const float* __restrict__ coeff, int T,
+                                                                float* __restrict__ out) {
+    // thread k sums tensor k's partials in index order; then a fixed-order tree over tensors
+    __shared__ float acc[REG_THREADS];
+    float v = 0.f;
+    for (int t = threadIdx.x; t < T; t += REG_THREADS) {
+        float s = 0.f;
+        for (int b = 0; b < REG_BLOCKS; ++b) s += partials[t * REG_BLOCKS + b];
+        v += coeff[t] * s;
+    }
+    acc[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = REG_THREADS / 2; o > 0; o >>= 1) {
+        if (threadIdx.x < o) acc[threadIdx.x] += acc[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+__global__ __launch_bounds__(REG_THREADS) void l2_grad_kernel(const float* const* __restrict__ ptrs,
+                                                              const long* __restrict__ numel,
+                                                              const float* __restrict__ coeff,
+                                                              const float* __restrict__ gscale,
+                                                              float* const* __restrict__ gptrs, int accumulate) {
+    const int t = blockIdx.y;
+    const float* __restrict__ w = ptrs[t];
+    float* __restrict__ g = gptrs[t];
+    const long n = numel[t];
+    const float sc = 2.f * coeff[t] * gscale[0];
+    const long stride = (long)gridDim.x * REG_THREADS;
+    for (long i = (long)blockIdx.x * REG_THREADS + threadIdx.x; i < n; i += stride)
+        g[i] = accumulate ? fmaf(sc, w[i], g[i]) : sc * w[i];
+}
+
+extern "C" {
+
+int xdfm_l2_reg_fwd(const float* const* ptrs, const long* numel, const float* coeff, int T, float* partials,
+                    float* out, void* stream) {
+    XDFM_REQUIRE(ptrs && numel && coeff && partials && out, "l2_reg_fwd: null pointer");
+    XDFM_REQUIRE(T > 0 && T <= 65535, "l2_reg_fwd: T=%d", T);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(l2_sumsq_kernel, dim3(REG_BLOCKS, T), dim3(REG_THREADS), 0, st, ptrs, numel, partials);
+    int rc = xdfm_check_launch("l2_reg_fwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(l2_finish_kernel, dim3(1), dim3(REG_THREADS), 0, st, partials, coeff, T, out);
+    return xdfm_check_launch("l2_reg_fwd finish");
+}
+
+int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* coeff, int T, const float* gscale,
+                    float* const* gptrs, int accumulate, void* stream) {
+    XDFM_REQUIRE(ptrs && numel && coeff && gscale && gptrs, "l2_reg_bwd: null pointer");
+    XDFM_REQUIRE(T > 0 && T <= 65535, "l2_reg_bwd: T=%d", T);
+    hipLaunchKernelGGL(l2_grad_kernel, dim3(REG_BLOCKS, T), dim3(REG_THREADS), 0, (hipStream_t)stream, ptrs, numel,
+                       coeff, gscale, gptrs, accumulate);
+    return xdfm_check_launch("l2_reg_bwd");
+}
+
+}  // extern "C"

@@ -298,3 +298,66 @@ def from_fm_layout(t: torch.Tensor, B: int, D: int) -> torch.Tensor:
     """FM layout [R, B*D] -> [B, R, D]."""
     R = t.shape[0]
     return t.view(R, B, D).permute(1, 0, 2)
+
+
+# --------------------------------------------------------------------------------------------- #
+# L2 regulariser                                                                                 #
+# --------------------------------------------------------------------------------------------- #
+class L2Plan:
+    """Device-side description (pointers, sizes, strengths) of the tensors one L2 term covers."""
+
+    def __init__(self, coeffs: Sequence[float]):
+        self.coeffs = [float(c) for c in coeffs]
+        self._key = None
+        self._dev = None
+
+    def tables(self, tensors: Sequence[torch.Tensor]):
+        key = tuple((t.data_ptr(), t.numel()) for t in tensors)
+        if key != self._key:
+            dev = tensors[0].device
+            self._dev = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=dev),
+                         torch.tensor([k[1] for k in key], dtype=torch.int64, device=dev),
+                         torch.tensor(self.coeffs, dtype=torch.float32, device=dev))
+            self._key = key
+        return self._dev
+
+
+class L2Reg(torch.autograd.Function):
+    """sum_t coeff_t * sum(w_t^2) -> tensor of shape [1]  (deepctr/models/basemodel.py:412-428, l1 == 0)."""
+
+    @staticmethod
+    def forward(ctx, plan: L2Plan, *tensors):
+        lib = _lib.load()
+        for t in tensors:
+            _need_cuda(t, "regularised tensor")
+            if not t.is_contiguous():
+                raise ValueError("xdfm: regularised tensors must be contiguous")
+        ptrs, numel, coeff = plan.tables(tensors)
+        T = len(tensors)
+        dev = tensors[0].device
+        partials = torch.empty(32 * T, dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.xdfm_l2_reg_fwd(_ptr(ptrs), _ptr(numel), _ptr(coeff), T, _ptr(partials), _ptr(out), _stream()),
+                   "l2_reg_fwd")
+        ctx.plan = plan
+        ctx.save_for_backward(*tensors)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        tensors = ctx.saved_tensors
+        ptrs, numel, coeff = ctx.plan.tables(tensors)
+        T = len(tensors)
+        dev = tensors[0].device
+        sizes = [t.numel() for t in tensors]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+        grads, off = [], 0
+        for t, n in zip(tensors, sizes):
+            grads.append(flat[off:off + n].view(t.shape))
+            off += n
+        gp = torch.tensor([x.data_ptr() for x in grads], dtype=torch.int64, device=dev)
+        gs = g.reshape(1).contiguous()
+        _lib.check(lib.xdfm_l2_reg_bwd(_ptr(ptrs), _ptr(numel), _ptr(coeff), T, _ptr(gs), _ptr(gp), 0, _stream()),
+                   "l2_reg_bwd")
+        return (None,) + tuple(grads)
