@@ -65,19 +65,9 @@ def build_model(cfg, vocab_size, device):
 
 
 def train_step(model, xb, yb, dp):
-    """basemodel.py:245-262 without the two .item() host syncs (losses stay on the device)."""
-    y_pred = model(xb).squeeze()
-    model.optim.zero_grad()
-    loss = torch.nn.functional.binary_cross_entropy(y_pred, yb.squeeze(), reduction="sum")
-    reg = model.get_regularization_loss()
-    if dp is None:
-        (loss + reg + model.aux_loss).backward()
-    else:
-        loss.backward()
-        dp.reduce_dense_grads(model)
-        (reg + model.aux_loss).backward()
-    model.optim.step()
-    return loss
+    """The body of the reference's batch loop (basemodel.py:245-262) as the model's own fit runs it,
+    without the two .item() host syncs (losses stay on the device)."""
+    return model.train_on_batch(xb, yb)[1]
 
 
 def usable_cores():

@@ -72,14 +72,16 @@ int xdfm_embed_gather_fwd(const float* X, long ldx, int B,
  * replaces: autograd of the above (aten::embedding_dense_backward x52, sparse=False,
  *           deepctr/inputs.py:168) and d(linear_model.weight).
  * d_emb_fm [m][B*D] or NULL, d_dnn_in [B][m*D+nd] or NULL, d_lin [B] or NULL are the incoming
- * gradients; d_tables / d_lin_tables are device arrays of m pointers to ZERO-INITIALISED dense
- * gradient tables which are accumulated into (fp32 atomics); d_dense_w [nd] is accumulated too.
+ * gradients.  The dense gradient tables live in ONE caller-initialised buffer d_flat (zeros, or the
+ * L2 gradient written by xdfm_l2_reg_bwd): table j starts at d_flat + tab_off[j], its linear table
+ * at d_flat + lin_off[j] (device long[m], element offsets; either may be NULL).  Row gradients are
+ * accumulated with fp32 atomics; d_dense_w [nd] is accumulated too.
  */
 int xdfm_embed_scatter_bwd(const float* X, long ldx, int B,
                            const int* cols, const int* vocab, int m, int D,
                            const int* dense_cols, int nd,
                            const float* d_emb_fm, const float* d_dnn_in, const float* d_lin,
-                           float* const* d_tables, float* const* d_lin_tables, float* d_dense_w,
+                           float* d_flat, const long* tab_off, const long* lin_off, float* d_dense_w,
                            void* stream);
 
 /* ------------------------------------------------------------------ CIN level (K3 / K4)
@@ -134,12 +136,13 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
  * ptrs: device array of T tensor base pointers, numel: device long[T], coeff: device float[T]
  * (the l2 strength of each tensor).  fwd: out[0] = sum_t coeff[t] * sum(w_t^2), deterministic;
  * partials: scratch of 32*T floats.  bwd: g_t = 2*coeff[t]*gscale[0]*w_t written (accumulate=0) or
- * added (accumulate=1) to the T buffers in gptrs; gscale is a device scalar.
+ * added (accumulate=1) at gflat + goff[t] (device long[T], element offsets); gscale is a device
+ * scalar.
  */
 int xdfm_l2_reg_fwd(const float* const* ptrs, const long* numel, const float* coeff, int T,
                     float* partials, float* out, void* stream);
 int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* coeff, int T,
-                    const float* gscale, float* const* gptrs, int accumulate, void* stream);
+                    const float* gscale, float* gflat, const long* goff, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

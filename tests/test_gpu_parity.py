@@ -64,7 +64,8 @@ def test_cin_layer_vs_reference_golden(name):
 
 
 @pytest.mark.parametrize("B,m,D,ls", [(130, 26, 16, (64, 32, 32)), (37, 7, 10, (40, 24)), (257, 26, 8, (128, 128)),
-                                       (70, 5, 32, (24, 10, 6)), (33, 26, 16, (256,))])
+                                       (70, 5, 32, (24, 10, 6)), (33, 26, 16, (256,)), (45, 22, 32, (136, 96)),
+                                       (19, 25, 4, (200, 66))])
 def test_cin_vs_oracle_random(B, m, D, ls):
     from deepctr.layers import CIN
     from oracle import xdeepfm_oracle as orc
@@ -332,11 +333,37 @@ def test_l2_regulariser_kernel_vs_torch():
         tensors.append(base[off:off + n].view(s).detach().requires_grad_(True))
         off += n
     plan = ops.L2Plan(coeffs)
-    val = ops.L2Reg.apply(plan, *tensors)
+    val = ops.L2Reg.apply(plan, None, 0, *tensors)
     want = sum(torch.sum(c * torch.square(t.detach().double())) for c, t in zip(coeffs, tensors))
     assert abs(val.item() - want.item()) <= 2e-6 * abs(want.item())
     (val * 3.0).sum().backward()
     for c, t in zip(coeffs, tensors):
         close(t.grad, (2 * c * 3.0 * t.detach()).cpu().numpy(), rtol=1e-6, atol=0)
     # deterministic: same bits on a second evaluation
-    assert ops.L2Reg.apply(plan, *tensors).item() == val.item()
+    assert ops.L2Reg.apply(plan, None, 0, *tensors).item() == val.item()
+
+
+def test_train_on_batch_matches_unfused_sequence():
+    """The model's own step hands the tables' L2 gradient to the gather's backward (deferred path);
+    the gradients must equal those of the plain loss + reg sequence the reference runs."""
+    dev = _dev()
+    g = load_golden("model_sum_small")
+    B = int(g["B"])
+    X, y = T(g["X"]).to(dev), T(g["y"]).to(dev)
+    grads = []
+    for fused in (False, True):
+        model = _build_model(g, dev)
+        model.load_state_dict({k[3:]: T(v) for k, v in g.items() if k.startswith("s0:")}, strict=True)
+        model.compile(torch.optim.SGD(model.parameters(), lr=0.0), "binary_crossentropy")
+        model.train()
+        if fused:
+            model.train_on_batch(X[:B], y[:B])
+        else:
+            yp = model(X[:B]).squeeze()
+            model.optim.zero_grad()
+            (torch.nn.functional.binary_cross_entropy(yp, y[:B].squeeze(), reduction="sum")
+             + model.get_regularization_loss() + model.aux_loss).backward()
+        grads.append({k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()})
+    for k in grads[0]:
+        gclose(grads[1][k], grads[0][k], k)
+        gclose(grads[1][k], g["g:" + k], "vs reference " + k)

@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], breg[4 * q4 + 1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], breg[4 * q4 + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], breg[4 * q4 + 3], acc, 0, 0, 0);
+                // pin the order: without this hipcc sinks every ring load down to its first use
+                // (one register quad, vmcnt(0) before each group) and the prefetch distance is lost
+                __builtin_amdgcn_sched_barrier(0);
             }
             g += HS4;
             // acc[r] = dZ[(i = iblk*32 + frag_row(r,s), j)][n]
@@ -266,6 +269,153 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v2 of the dW kernel: operands reach LDS by LDS-DMA (global_load_lds_dword: no staging registers,
+// asynchronous), two LDS buffers, so the loads of chunk c+1 run under the MFMAs of chunk c.
+// LDS image of every region: element (row, col) at row*32 + (col ^ (row & 31)) -- the DMA writes
+// lane-linear, so the swizzle is applied to each lane's SOURCE column; the fragment reads (32 lanes =
+// 32 rows, same logical column) then touch 32 different banks.
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+__device__ __forceinline__ void dma_dword(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)lds_wave_base, 4, 0, 0);
+}
+
+template <int MT, int JT>
+__global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
+    const float* __restrict__ dOut, const float* __restrict__ xp, const float* __restrict__ x0,
+    int H, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad, int IPAD,
+    float* __restrict__ dWt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(JT == 2, "one DMA instruction stages exactly two x0 rows");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, s = lane >> 5;
+    const int wt0 = blockIdx.x * 4;
+    const int hg = wt0 / TPH;
+    const int tin = wt0 + wave - hg * TPH;
+    const bool active = tin < JP * IB;
+    const int jp = active ? tin / IB : 0;
+    const int iblk = active ? tin - jp * IB : 0;
+    const long n_begin = (long)blockIdx.y * n_per_split;
+    const long n_end = (n_begin + n_per_split < N) ? n_begin + n_per_split : N;
+    const int nfull = (int)((n_end - n_begin) / BWW_NC);          // chunks with all 32 columns < n_end
+
+    constexpr int DROWS = 32 * MT;                      // dOut rows per h-group
+    constexpr int WROWS = 32 + JT;                      // per-wave rows: x_prev block + x0 rows
+    constexpr int BUF = (DROWS + 4 * WROWS) * 32;       // floats per LDS buffer
+    constexpr int NDMA = DROWS / 8 + 16 + 1;            // DMA instructions per wave per chunk
+
+    // DMA instruction k of a region covers rows (2k, 2k+1): lane (c, s) fetches row 2k+s, logical
+    // column c ^ ((2k+s) & 31), and the hardware drops it at word 64k + lane of the region.
+    // Addresses are recomputed per instruction from a few scalars to keep the VGPR budget for acc.
+    const int j_own = jp * JT + s;
+    const float* src0 = x0 + (long)(j_own < m ? j_own : m - 1) * N;
+    const int drow0 = wave * (DROWS / 4);               // first dOut row (within the h-group) of this wave
+
+    auto issue = [&](long nc0, int buf) {
+        float* base = smem + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < DROWS / 8; ++k) {
+            const int row = drow0 + 2 * k + s;
+            int h = hg * DROWS + row;
+            h = h < H ? h : H - 1;
+            dma_dword(dOut + (long)h * N + nc0 + (c ^ (row & 31)), base + (drow0 + 2 * k) * 32);
+        }
+        float* wb = base + DROWS * 32 + wave * (WROWS * 32);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            int i = iblk * 32 + 2 * k + s;
+            i = i < Hp ? i : Hp - 1;
+            dma_dword(xp + (long)i * N + nc0 + (c ^ (2 * k + s)), wb + (2 * k) * 32);
+        }
+        dma_dword(src0 + nc0 + (c ^ s), wb + 32 * 32);
+    };
+
+    f32x16 acc[MT][JT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][jt][r] = 0.f;
+
+    auto compute = [&](int buf) {
+        const float* dS = smem + buf * BUF;
+        const float* xS = dS + DROWS * 32 + wave * (WROWS * 32);
+        const float* zS = xS + 32 * 32;
+#pragma unroll 4
+        for (int t = 0; t < BWW_NC / 2; ++t) {
+            const int col = 2 * t + s;
+            float a[MT], b[JT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) a[mt] = dS[(mt * 32 + c) * 32 + (col ^ c)];
+            const float xv = xS[c * 32 + (col ^ c)];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) b[jt] = xv * zS[jt * 32 + (col ^ jt)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt], b[jt], acc[mt][jt], 0, 0, 0);
+        }
+    };
+
+    if (nfull > 0) issue(n_begin, 0);
+    for (int ch = 0; ch < nfull; ++ch) {
+        if (ch + 1 < nfull) {
+            issue(n_begin + (long)(ch + 1) * BWW_NC, (ch + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // chunk ch landed, ch+1 in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        compute(ch & 1);
+        __builtin_amdgcn_s_barrier();          // everyone is done with buf[ch&1] before it is refilled
+    }
+    // tail chunk with fewer than 32 valid columns: masked register staging into buffer 0
+    const long nt0 = n_begin + (long)nfull * BWW_NC;
+    if (nt0 < n_end) {
+        float* base = smem;
+        const long n = nt0 + c;
+        const float cm = (n < n_end) ? 1.f : 0.f;
+        const long ncl = n < N ? n : N - 1;
+#pragma unroll
+        for (int k = 0; k < DROWS / 8; ++k) {
+            const int row = drow0 + 2 * k + s;
+            const int h = hg * DROWS + row;
+            base[row * 32 + (c ^ (row & 31))] = dOut[(long)(h < H ? h : H - 1) * N + ncl] * ((h < H) ? cm : 0.f);
+        }
+        float* wb = base + DROWS * 32 + wave * (WROWS * 32);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = 2 * k + s;
+            const int i = iblk * 32 + row;
+            wb[row * 32 + (c ^ row)] = xp[(long)(i < Hp ? i : Hp - 1) * N + ncl] * ((i < Hp) ? cm : 0.f);
+        }
+        wb[(32 + s) * 32 + (c ^ s)] = src0[ncl] * ((j_own < m) ? cm : 0.f);
+        __syncthreads();
+        compute(0);
+    }
+
+    if (!active) return;
+    const int i = iblk * 32 + c;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j = jp * JT + jt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = hg * 32 * MT + mt * 32 + frag_row(r, s);
+                if (h < H && i < Hp && j < m)
+                    atomicAdd(&dWt[((long)j * Hpad + h) * IPAD + i], acc[mt][jt][r]);
+            }
+        }
+}
+
 __global__ void cin_bwd_w_unpack_kernel(const float* __restrict__ dWt, int H, int Hp, int m, int Hpad,
                                         int IPAD, float* __restrict__ dW) {
     const long K = (long)Hp * m;
@@ -287,8 +437,9 @@ template <int HS4>
 static int launch_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
                         int m, long N, float* dxp, float* dx0, hipStream_t st) {
     const int IB = ceil_div(Hp, 32);
-    const size_t lds = (size_t)4 * m * 32 * sizeof(float);
+    size_t lds = (size_t)4 * m * 32 * sizeof(float);
     if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds);
+    if (xdfm_opt(OPT_DBG) & 4) lds = 80 * 1024;
     hipLaunchKernelGGL((cin_bwd_x_kernel<HS4>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, Wz, H,
                        Hp, m, N, IB, dxp, dx0);
     return xdfm_check_launch("cin_level_bwd_x");
@@ -307,7 +458,9 @@ static int launch_bwd_w(const float* dOut, const float* xp, const float* x0, int
     const int gx = HG * TPH / 4;
     int nsplit = xdfm_opt(OPT_BWW_NSPLIT);
     const int max_split = ceil_div(N, BWW_NC);
-    if (nsplit <= 0) nsplit = ceil_div(1024, gx);
+    // default: one resident round -- 2 workgroups per CU (LDS / VGPR limit) x 256 CUs.  More splits
+    // only add atomic traffic and a ragged last round (1027 workgroups on 512 slots ran 3 rounds).
+    if (nsplit <= 0) nsplit = 512 / gx > 0 ? 512 / gx : 1;
     if (nsplit > max_split) nsplit = max_split;
     if (nsplit > 65535) nsplit = 65535;
     const long n_per_split = round_up(ceil_div(N, nsplit), BWW_NC);
@@ -315,9 +468,15 @@ static int launch_bwd_w(const float* dOut, const float* xp, const float* x0, int
     const size_t ws_bytes = (size_t)m * Hpad * IPAD * sizeof(float);
     hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, st);
     if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_level_bwd_w memset: %s", hipGetErrorString(e));
-    const size_t lds = (size_t)(32 * MT + 4 * (32 + JT)) * BWW_PITCH * sizeof(float);
-    hipLaunchKernelGGL((cin_bwd_w_kernel<MT, JT>), dim3(gx, nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp, m, N,
-                       IB, JP, TPH, n_per_split, Hpad, IPAD, ws);
+    if (xdfm_opt(OPT_DBG) & 8) {      // v1: register staging, single LDS buffer
+        const size_t lds = (size_t)(32 * MT + 4 * (32 + JT)) * BWW_PITCH * sizeof(float);
+        hipLaunchKernelGGL((cin_bwd_w_kernel<MT, JT>), dim3(gx, nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp, m,
+                           N, IB, JP, TPH, n_per_split, Hpad, IPAD, ws);
+    } else {
+        const size_t lds = (size_t)2 * (32 * MT + 4 * (32 + JT)) * 32 * sizeof(float);
+        hipLaunchKernelGGL((cin_bwd_w_dma_kernel<MT, JT>), dim3(gx, nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp,
+                           m, N, IB, JP, TPH, n_per_split, Hpad, IPAD, ws);
+    }
     int rc = xdfm_check_launch("cin_level_bwd_w");
     if (rc) return rc;
     const long total = (long)H * Hp * m;

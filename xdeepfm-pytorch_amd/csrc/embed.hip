@@ -94,7 +94,8 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
 __global__ __launch_bounds__(256) void embed_scatter_kernel(
     const float* __restrict__ X, long ldx, int B, const int* __restrict__ cols, const int* __restrict__ vocab, int m,
     int D, int nd, const float* __restrict__ d_emb_fm, const float* __restrict__ d_dnn_in,
-    const float* __restrict__ d_lin, float* const* __restrict__ d_tables, float* const* __restrict__ d_lin_tables) {
+    const float* __restrict__ d_lin, float* __restrict__ d_flat, const long* __restrict__ tab_off,
+    const long* __restrict__ lin_off) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)B * m * D;
     if (idx >= total) return;
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(
     float g = 0.f;
     if (d_emb_fm) g += d_emb_fm[((long)j * B + b) * D + d];
     if (d_dnn_in) g += d_dnn_in[(long)b * ((long)m * D + nd) + (long)j * D + d];
-    if (d_tables) atomicAdd(d_tables[j] + id * D + d, g);
-    if (d == 0 && d_lin && d_lin_tables) atomicAdd(d_lin_tables[j] + id, d_lin[b]);
+    if (tab_off) atomicAdd(d_flat + tab_off[j] + id * D + d, g);
+    if (d == 0 && d_lin && lin_off) atomicAdd(d_flat + lin_off[j] + id, d_lin[b]);
 }
 
 // d(linear_model.weight)[k] += sum_b X[b][dense_cols[k]] * d_lin[b]
@@ -161,15 +162,16 @@ int xdfm_embed_gather_fwd(const float* X, long ldx, int B, const float* const* t
 
 int xdfm_embed_scatter_bwd(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
                            const int* dense_cols, int nd, const float* d_emb_fm, const float* d_dnn_in,
-                           const float* d_lin, float* const* d_tables, float* const* d_lin_tables,
+                           const float* d_lin, float* d_flat, const long* tab_off, const long* lin_off,
                            float* d_dense_w, void* stream) {
     XDFM_REQUIRE(X && cols && vocab, "embed_scatter_bwd: null pointer");
+    XDFM_REQUIRE(d_flat || (!tab_off && !lin_off), "embed_scatter_bwd: offsets without a gradient buffer");
     XDFM_REQUIRE(B > 0 && m > 0 && D > 0 && nd >= 0, "embed_scatter_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    if (d_tables || (d_lin && d_lin_tables)) {
+    if (tab_off || (d_lin && lin_off)) {
         const long total = (long)B * m * D;
         hipLaunchKernelGGL(embed_scatter_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, X, ldx, B, cols, vocab,
-                           m, D, nd, d_emb_fm, d_dnn_in, d_lin, d_tables, d_lin_tables);
+                           m, D, nd, d_emb_fm, d_dnn_in, d_lin, d_flat, tab_off, lin_off);
         int rc = xdfm_check_launch("embed_scatter_bwd");
         if (rc) return rc;
     }

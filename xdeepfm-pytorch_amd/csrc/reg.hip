@@ -60,10 +60,11 @@ __global__ __launch_bounds__(REG_THREADS) void l2_grad_kernel(const float* const
                                                               const long* __restrict__ numel,
                                                               const float* __restrict__ coeff,
                                                               const float* __restrict__ gscale,
-                                                              float* const* __restrict__ gptrs, int accumulate) {
+                                                              float* __restrict__ gflat,
+                                                              const long* __restrict__ goff, int accumulate) {
     const int t = blockIdx.y;
     const float* __restrict__ w = ptrs[t];
-    float* __restrict__ g = gptrs[t];
+    float* __restrict__ g = gflat + goff[t];
     const long n = numel[t];
     const float sc = 2.f * coeff[t] * gscale[0];
     const long stride = (long)gridDim.x * REG_THREADS;
@@ -86,11 +87,11 @@ int xdfm_l2_reg_fwd(const float* const* ptrs, const long* numel, const float* co
 }
 
 int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* coeff, int T, const float* gscale,
-                    float* const* gptrs, int accumulate, void* stream) {
-    XDFM_REQUIRE(ptrs && numel && coeff && gscale && gptrs, "l2_reg_bwd: null pointer");
+                    float* gflat, const long* goff, int accumulate, void* stream) {
+    XDFM_REQUIRE(ptrs && numel && coeff && gscale && gflat && goff, "l2_reg_bwd: null pointer");
     XDFM_REQUIRE(T > 0 && T <= 65535, "l2_reg_bwd: T=%d", T);
     hipLaunchKernelGGL(l2_grad_kernel, dim3(REG_BLOCKS, T), dim3(REG_THREADS), 0, (hipStream_t)stream, ptrs, numel,
-                       coeff, gscale, gptrs, accumulate);
+                       coeff, gscale, gflat, goff, accumulate);
     return xdfm_check_launch("l2_reg_bwd");
 }
 

@@ -17,6 +17,7 @@ enum {
     OPT_FWD_NF = 0,      // column fragments (32 cols each) per wave in the forward kernel: 1 or 2
     OPT_BWW_NSPLIT,      // 0 = auto; n-range splits of the dW kernel
     OPT_BWW_SLAB,        // 1 = deterministic slab reduction instead of atomics (reserved)
+    OPT_DBG,             // timing experiments only (results become wrong): bit0 = A operand from one cached line
     OPT_COUNT
 };
 

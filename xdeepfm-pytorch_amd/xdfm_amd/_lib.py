@@ -24,7 +24,7 @@ SIGNATURES = {
     "xdfm_set_option": (c_int, [c_char_p, c_int]),
     "xdfm_get_option": (c_int, [c_char_p]),
     "xdfm_embed_gather_fwd": (c_int, [P, c_long, c_int, P, P, P, P, c_int, c_int, P, P, c_int, P, P, P, P, P]),
-    "xdfm_embed_scatter_bwd": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P]),
+    "xdfm_embed_scatter_bwd": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P]),
     "xdfm_cin_fwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_fwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "xdfm_cin_level_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_int, P, P]),
@@ -37,7 +37,7 @@ SIGNATURES = {
     "xdfm_cin_bwd_w_ws_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_level_bwd_w": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_l2_reg_fwd": (c_int, [P, P, P, c_int, P, P, P]),
-    "xdfm_l2_reg_bwd": (c_int, [P, P, P, c_int, P, P, c_int, P]),
+    "xdfm_l2_reg_bwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
 }
 
 ABI_VERSION = 1

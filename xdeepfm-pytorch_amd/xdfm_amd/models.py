@@ -198,11 +198,14 @@ class BaseModel(nn.Module):
         weight_list = [weight_list] if isinstance(weight_list, nn.parameter.Parameter) else list(weight_list)
         self.regularization_weight.append((weight_list, l1, l2))
 
-    def get_regularization_loss(self):
+    def get_regularization_loss(self, _defer_tables=False):
         """sum over groups of l1*|w| + l2*w^2 (basemodel.py:412-428), shape [1].  All l2 groups are
-        evaluated by one multi-tensor launch (K6) instead of four ATen calls per tensor."""
-        tensors, coeffs = [], []
-        total = None
+        evaluated by one multi-tensor launch (K6) instead of four ATen calls per tensor.
+
+        `_defer_tables` is used by the model's own train step only: the L2 gradient of the embedding
+        tables is then produced inside the gather's backward (as the initial value of the dense table
+        gradients) instead of as separate table-sized tensors that autograd has to add."""
+        l2_terms, total = [], None
         for weight_list, l1, l2 in self.regularization_weight:
             for w in weight_list:
                 p = w[1] if isinstance(w, tuple) else w
@@ -210,17 +213,52 @@ class BaseModel(nn.Module):
                     term = torch.sum(l1 * torch.abs(p))
                     total = term if total is None else total + term
                 if l2 > 0:
-                    tensors.append(p)
-                    coeffs.append(l2)
-        if tensors:
-            plan = getattr(self, "_l2_plan", None)
-            if plan is None or plan.coeffs != [float(c) for c in coeffs]:
-                plan = self._l2_plan = ops.L2Plan(coeffs)
-            term = ops.L2Reg.apply(plan, *tensors)
+                    l2_terms.append((p, float(l2)))
+        if l2_terms:
+            cache = self.__dict__.setdefault("_l2_cache", {})
+            embed_plan, n_defer = None, 0
+            if _defer_tables and self._plan is not None and getattr(self, "_fused_linear", False) \
+                    and self._plan.dp is None:
+                tables = [self.embedding_dict[fc.embedding_name].weight for fc in self._sparse_cols] + \
+                    self.linear_model.tables()
+                coeff_of = {id(p): c for p, c in l2_terms}
+                if all(id(t) in coeff_of for t in tables) and all(t.requires_grad for t in tables):
+                    ids = {id(t) for t in tables}
+                    l2_terms = [(t, coeff_of[id(t)]) for t in tables] + [x for x in l2_terms if id(x[0]) not in ids]
+                    embed_plan, n_defer = self._plan, len(tables)
+            term = ops.l2_regulariser([p for p, _ in l2_terms], [c for _, c in l2_terms], cache, embed_plan, n_defer)
             total = term if total is None else total + term
         if total is None:
             total = torch.zeros((1,), device=self.device)
         return total.reshape(1)
+
+    def train_on_batch(self, x, y):
+        """One optimisation step = the body of the reference's batch loop (basemodel.py:245-262):
+        forward, BCE(sum) + L2 (+ aux), backward, optimizer step.  Returns (y_pred, data_loss,
+        total_loss) as device tensors -- no host synchronisation."""
+        y_pred = self(x).squeeze()
+        self.optim.zero_grad()
+        loss_func = self.loss_func
+        if isinstance(loss_func, list):
+            assert len(loss_func) == self.num_tasks, "the length of `loss_func` should be equal with `self.num_tasks`"
+            loss = sum(loss_func[i](y_pred[:, i], y[:, i], reduction='sum') for i in range(self.num_tasks))
+        else:
+            loss = loss_func(y_pred, y.squeeze(), reduction='sum')
+        dp = xdist.current()
+        if dp is None:
+            reg_loss = self.get_regularization_loss(_defer_tables=True)
+            total_loss = loss + reg_loss + self.aux_loss
+            total_loss.backward()
+        else:
+            # data-loss gradients are SUMMED over ranks (the loss is a sum over the global batch); the
+            # L2 term is identical on every replica and is added once, locally, after the reduce.
+            reg_loss = self.get_regularization_loss()
+            loss.backward()
+            dp.reduce_dense_grads(self)
+            (reg_loss + self.aux_loss).backward()
+            total_loss = loss.detach() + reg_loss.detach() + self.aux_loss
+        self.optim.step()
+        return y_pred, loss, total_loss
 
     def add_auxiliary_loss(self, aux_loss, alpha):
         self.aux_loss = aux_loss * alpha
@@ -320,8 +358,7 @@ class BaseModel(nn.Module):
         data = Data.TensorDataset(torch.from_numpy(self._as_matrix(x)), torch.from_numpy(y))
         if batch_size is None:
             batch_size = 256
-        model = self.train()
-        loss_func, optim = self.loss_func, self.optim
+        self.train()
         dp = xdist.current()
         if dp is not None and verbose > 0:
             print("row-parallel on %d ranks (RCCL), global batch %d" % (dp.world, batch_size * dp.world))
@@ -352,28 +389,11 @@ class BaseModel(nn.Module):
                         xb, yb = dp.shard(xb), dp.shard(yb)
                     xd = xb.to(self.device).float()
                     yd = yb.to(self.device).float()
-                    y_pred = model(xd).squeeze()
-                    optim.zero_grad()
-                    if isinstance(loss_func, list):
-                        assert len(loss_func) == self.num_tasks, \
-                            "the length of `loss_func` should be equal with `self.num_tasks`"
-                        loss = sum(loss_func[i](y_pred[:, i], yd[:, i], reduction='sum')
-                                   for i in range(self.num_tasks))
-                    else:
-                        loss = loss_func(y_pred, yd.squeeze(), reduction='sum')
-                    reg_loss = self.get_regularization_loss()
+                    y_pred, loss, total_loss = self.train_on_batch(xd, yd)
                     if dp is None:
-                        total_loss = loss + reg_loss + self.aux_loss
                         total_loss_epoch += total_loss.item()
-                        total_loss.backward()
                     else:
-                        # data-loss gradients are SUMMED over ranks (the loss is a sum over the global
-                        # batch); the L2 term is identical on every replica and is added once, locally.
-                        loss.backward()
-                        dp.reduce_dense_grads(self)
-                        (reg_loss + self.aux_loss).backward()
-                        total_loss_epoch += dp.sum_scalar(loss.detach()) + (reg_loss + self.aux_loss).item()
-                    optim.step()
+                        total_loss_epoch += dp.sum_scalar(loss.detach()) + (total_loss - loss.detach()).item()
                     if verbose > 0:
                         yt, yp = yd, y_pred
                         if dp is not None:

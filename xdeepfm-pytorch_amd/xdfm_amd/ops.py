@@ -68,7 +68,9 @@ class EmbedPlan:
         self.dense_cols = [int(c) for c in dense_cols]
         self._dev = {}
         self._ptr_cache = {}
+        self._off_cache = {}
         self.dp = None            # set by xdfm_amd.dist to exchange row gradients across ranks
+        self.reg_defer = None     # (gscale, L2Plan) left by L2Reg.backward: table L2 gradient still owed
 
     def on(self, device):
         key = str(device)
@@ -87,6 +89,20 @@ class EmbedPlan:
             hit = (ptrs, torch.tensor(ptrs, dtype=torch.int64, device=tensors[0].device))
             self._ptr_cache[tag] = hit
         return hit[1]
+
+    def grad_layout(self, shapes, device):
+        """Element offsets of every table gradient inside the flat gradient buffer (device int64)."""
+        key = (tuple(shapes), str(device))
+        hit = self._off_cache.get(key)
+        if hit is None:
+            sizes = [sh[0] * sh[1] for sh in shapes]
+            offs, off = [], 0
+            for n in sizes:
+                offs.append(off)
+                off += n
+            hit = (sizes, offs, off, torch.tensor(offs, dtype=torch.int64, device=device))
+            self._off_cache[key] = hit
+        return hit
 
     def check_ids(self, device) -> bool:
         """True when a gather since the last call saw an id outside [0, vocab) (syncs the stream)."""
@@ -127,28 +143,39 @@ class EmbedGather(torch.autograd.Function):
             _ptr(X), X.stride(0), B, _ptr(tp), _ptr(lp), _ptr(cols), _ptr(vocab), m, D,
             _ptr(dcols) if nd else None, _ptr(dw), nd, _ptr(emb_fm), _ptr(dnn_in), _ptr(lin), _ptr(flag),
             _stream())), "embed_gather_fwd")
+        plan.reg_defer = None      # a deferral is only valid between this forward and its backward
         ctx.plan, ctx.has_lin = plan, has_lin
         ctx.shapes = [tuple(t.shape) for t in tables]
-        ctx.save_for_backward(X)
+        ctx.save_for_backward(X, *tables)
         return emb_fm, dnn_in, lin
 
     @staticmethod
     def backward(ctx, d_emb, d_dnn, d_lin):
-        (X,) = ctx.saved_tensors
+        X = ctx.saved_tensors[0]
+        tables = ctx.saved_tensors[1:]
         plan, has_lin = ctx.plan, ctx.has_lin
         lib = _lib.load()
         m, D, nd = plan.m, plan.D, plan.nd
         dev = X.device
-        sizes = [s[0] * s[1] for s in ctx.shapes]
-        flat = torch.zeros(sum(sizes) + max(nd, 1), dtype=torch.float32, device=dev)
-        grads, off = [], 0
-        for s, n in zip(ctx.shapes, sizes):
-            grads.append(flat[off:off + n].view(s))
-            off += n
-        d_w = flat[off:off + nd].view(nd, 1) if nd else None
+        sizes, offs, total, off_dev = plan.grad_layout(ctx.shapes, dev)
+        # ONE buffer holds every dense table gradient (+ the dense-weight gradient at its end).  It
+        # starts as zeros, or -- when L2Reg.backward deferred the tables' L2 term to us -- as
+        # 2*l2*gscale*w, which saves a memset, a table-sized temporary and one add per table.
+        defer, plan.reg_defer = plan.reg_defer, None
+        if defer is not None:
+            gscale, l2plan = defer
+            flat = torch.empty(total + max(nd, 1), dtype=torch.float32, device=dev)
+            flat[total:].zero_()
+            ptrs, numel, coeff = l2plan.tables(tables)
+            _lib.check(lib.xdfm_l2_reg_bwd(_ptr(ptrs), _ptr(numel), _ptr(coeff), len(tables), _ptr(gscale),
+                                           _ptr(flat), _ptr(off_dev), 0, _stream()), "l2_reg_bwd (deferred)")
+        else:
+            flat = torch.zeros(total + max(nd, 1), dtype=torch.float32, device=dev)
+        grads = [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, ctx.shapes)]
+        d_w = flat[total:total + nd].view(nd, 1) if nd else None
         cols, vocab, dcols, _ = plan.on(dev)
-        gp = torch.tensor([g.data_ptr() for g in grads[:m]], dtype=torch.int64, device=dev)
-        lp = torch.tensor([g.data_ptr() for g in grads[m:2 * m]], dtype=torch.int64, device=dev) if has_lin else None
+        tab_off = off_dev[:m]
+        lin_off = off_dev[m:2 * m] if has_lin else None
         pieces = [(X, d_emb, d_dnn, d_lin)]
         if plan.dp is not None:
             pieces = plan.dp.exchange_rows(X, d_emb, d_dnn, d_lin)
@@ -160,7 +187,8 @@ class EmbedGather(torch.autograd.Function):
             nbytes = B * (4 * (m + nd) + 2 * 4 * m * D + 4 + 4 * m * (D + 1))
             _lib.check(_run("embed_scatter_bwd[bytes]", nbytes, lambda: lib.xdfm_embed_scatter_bwd(
                 _ptr(Xr), Xr.stride(0), B, _ptr(cols), _ptr(vocab), m, D, _ptr(dcols) if nd else None, nd,
-                _ptr(de), _ptr(dd), _ptr(dl), _ptr(gp), _ptr(lp), _ptr(d_w), _stream())), "embed_scatter_bwd")
+                _ptr(de), _ptr(dd), _ptr(dl), _ptr(flat), _ptr(tab_off), _ptr(lin_off), _ptr(d_w), _stream())),
+                "embed_scatter_bwd")
         need_w = ctx.needs_input_grad[1]
         return (None, d_w if (need_w and nd) else None, None, None) + tuple(grads)
 
@@ -315,18 +343,32 @@ class L2Plan:
         key = tuple((t.data_ptr(), t.numel()) for t in tensors)
         if key != self._key:
             dev = tensors[0].device
+            offs, off = [], 0
+            for k in key:
+                offs.append(off)
+                off += k[1]
             self._dev = (torch.tensor([k[0] for k in key], dtype=torch.int64, device=dev),
                          torch.tensor([k[1] for k in key], dtype=torch.int64, device=dev),
                          torch.tensor(self.coeffs, dtype=torch.float32, device=dev))
+            self._offsets = (offs, off, torch.tensor(offs, dtype=torch.int64, device=dev))
             self._key = key
         return self._dev
 
+    def offsets(self):
+        return self._offsets
+
 
 class L2Reg(torch.autograd.Function):
-    """sum_t coeff_t * sum(w_t^2) -> tensor of shape [1]  (deepctr/models/basemodel.py:412-428, l1 == 0)."""
+    """sum_t coeff_t * sum(w_t^2) -> tensor of shape [1]  (deepctr/models/basemodel.py:412-428, l1 == 0).
+
+    `defer` = (EmbedPlan, L2Plan of the first n_defer tensors, L2Plan of the others) or None.  When
+    given, the first n_defer tensors are exactly the tables of that gather, in its order: their L2
+    gradient is not returned here but handed to EmbedGather.backward, which uses it as the initial
+    content of the dense table gradients it has to build anyway.  Only the model's own train step
+    passes `defer` (it guarantees that the gather's backward runs in the same pass)."""
 
     @staticmethod
-    def forward(ctx, plan: L2Plan, *tensors):
+    def forward(ctx, plan: L2Plan, defer, n_defer, *tensors):
         lib = _lib.load()
         for t in tensors:
             _need_cuda(t, "regularised tensor")
@@ -339,7 +381,7 @@ class L2Reg(torch.autograd.Function):
         out = torch.empty(1, dtype=torch.float32, device=dev)
         _lib.check(lib.xdfm_l2_reg_fwd(_ptr(ptrs), _ptr(numel), _ptr(coeff), T, _ptr(partials), _ptr(out), _stream()),
                    "l2_reg_fwd")
-        ctx.plan = plan
+        ctx.plan, ctx.defer, ctx.n_defer = plan, defer, n_defer
         ctx.save_for_backward(*tensors)
         return out
 
@@ -347,17 +389,32 @@ class L2Reg(torch.autograd.Function):
     def backward(ctx, g):
         lib = _lib.load()
         tensors = ctx.saved_tensors
-        ptrs, numel, coeff = ctx.plan.tables(tensors)
-        T = len(tensors)
-        dev = tensors[0].device
-        sizes = [t.numel() for t in tensors]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-        grads, off = [], 0
-        for t, n in zip(tensors, sizes):
-            grads.append(flat[off:off + n].view(t.shape))
-            off += n
-        gp = torch.tensor([x.data_ptr() for x in grads], dtype=torch.int64, device=dev)
         gs = g.reshape(1).contiguous()
-        _lib.check(lib.xdfm_l2_reg_bwd(_ptr(ptrs), _ptr(numel), _ptr(coeff), T, _ptr(gs), _ptr(gp), 0, _stream()),
-                   "l2_reg_bwd")
-        return (None,) + tuple(grads)
+        skip, plan = 0, ctx.plan
+        if ctx.defer is not None:
+            embed_plan, sub_plan, plan = ctx.defer
+            embed_plan.reg_defer = (gs, sub_plan)
+            skip = ctx.n_defer
+        rest = tensors[skip:]
+        grads = [None] * skip
+        if rest:
+            ptrs, numel, coeff = plan.tables(rest)
+            offs, total, off_dev = plan.offsets()
+            flat = torch.empty(total, dtype=torch.float32, device=rest[0].device)
+            _lib.check(lib.xdfm_l2_reg_bwd(_ptr(ptrs), _ptr(numel), _ptr(coeff), len(rest), _ptr(gs), _ptr(flat),
+                                           _ptr(off_dev), 0, _stream()), "l2_reg_bwd")
+            grads += [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, rest)]
+        return (None, None, None) + tuple(grads)
+
+
+def l2_regulariser(tensors, coeffs, cache: dict, embed_plan=None, n_defer=0):
+    """Evaluate the L2 term with plans cached in `cache` (a dict owned by the model)."""
+    n_defer = n_defer if embed_plan is not None else 0
+    key = (tuple(float(c) for c in coeffs), n_defer)
+    plans = cache.get(key)
+    if plans is None:
+        plans = cache[key] = (L2Plan(coeffs), L2Plan(coeffs[:n_defer]) if n_defer else None,
+                              L2Plan(coeffs[n_defer:]) if n_defer and len(coeffs) > n_defer else None)
+    full, sub, rest = plans
+    defer = (embed_plan, sub, rest) if n_defer else None
+    return L2Reg.apply(full, defer, n_defer, *tensors)
