@@ -1,0 +1,123 @@
+"""Row-parallel data parallelism (xdfm_amd/dist.py) with world_size 2.
+
+CPU test (gloo): the product's `fit` loop + RowParallel are driven with a model whose forward /
+regulariser are the CPU oracle (tests may use the oracle; the product never does), and must
+reproduce the single-process run on the concatenated batches -- the only way to check the N>1
+semantics (SUM of data-loss gradients, L2 applied once, History aggregation) without N GPUs.
+
+GPU test (gloo, both ranks on cuda:0): the real HIP path incl. the all-gathered row-gradient
+exchange of the embedding scatter against the single-process GPU run.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import PKG, ROOT
+
+VOCAB, ND, D = [9, 6, 12, 5, 7], 2, 4
+CIN, DNN = (6, 4), (8,)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_model(device, oracle_backed):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from oracle import xdeepfm_oracle as orc
+    names = ["C%d" % (i + 1) for i in range(len(VOCAB))]
+    dnames = ["I%d" % (i + 1) for i in range(ND)]
+    cols = [SparseFeat(n, v, D) for n, v in zip(names, VOCAB)] + [DenseFeat(n, 1) for n in dnames]
+    spec = orc.Spec(names, VOCAB, dnames, D, CIN, True, "relu", DNN, l2_reg_dnn=1e-5)
+
+    class OracleBacked(xDeepFM):
+        """Product fit loop + product DP logic, arithmetic by the CPU oracle."""
+
+        def forward(self, X):
+            return orc.model_forward(X, dict(self.named_parameters()), spec)
+
+        def get_regularization_loss(self, _defer_tables=False):
+            return orc.regularization_loss(dict(self.named_parameters()), spec)
+
+    cls = OracleBacked if oracle_backed else xDeepFM
+    model = cls(cols, cols, dnn_hidden_units=DNN, cin_layer_size=CIN, l2_reg_dnn=1e-5, device=device)
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+    for pg in model.optim.param_groups:
+        pg["lr"] = 1e-2
+    return model, names + dnames, orc
+
+
+def _data(orc):
+    X, y = orc.synthetic_batch(150, VOCAB, ND, seed=5)       # 150 rows: ragged last batch (150 = 2*64 + 22)
+    Xv, yv = orc.synthetic_batch(40, VOCAB, ND, seed=6)
+    return X, y, Xv, yv
+
+
+def _run(device, oracle_backed, per_rank_bs):
+    model, names, orc = _make_model(device, oracle_backed)
+    X, y, Xv, yv = _data(orc)
+    hist = model.fit({n: X[:, i] for i, n in enumerate(names)}, y, batch_size=per_rank_bs, epochs=2, verbose=2,
+                     validation_data=({n: Xv[:, i] for i, n in enumerate(names)}, yv), shuffle=True)
+    state = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    return {k: list(v) for k, v in hist.history.items()}, state
+
+
+def _worker(rank, world, port, device, oracle_backed, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hist, state = _run(device, oracle_backed, per_rank_bs=32)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), hist_keys=np.array(sorted(hist)),
+                 hist_vals=np.array([hist[k] for k in sorted(hist)]), **{"p:" + k: v for k, v in state.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+def _check(tmp_path, device, oracle_backed, rtol, atol):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, device, oracle_backed, str(tmp_path)), nprocs=2, join=True)
+    hist1, state1 = _run(device, oracle_backed, per_rank_bs=64)          # single process, global batch 64
+    r0 = np.load(str(tmp_path / "rank0.npz"))
+    r1 = np.load(str(tmp_path / "rank1.npz"))
+    keys = [str(k) for k in r0["hist_keys"]]
+    assert keys == sorted(hist1)
+    np.testing.assert_allclose(r0["hist_vals"], np.array([hist1[k] for k in keys]), rtol=rtol, atol=atol)
+    np.testing.assert_allclose(r1["hist_vals"], r0["hist_vals"], rtol=1e-6, atol=1e-7)   # every rank logs the same
+    for k, v in state1.items():
+        np.testing.assert_allclose(r0["p:" + k], v, rtol=rtol, atol=atol, err_msg=k)
+        np.testing.assert_allclose(r1["p:" + k], r0["p:" + k], rtol=0, atol=1e-7, err_msg="replicas differ: " + k)
+
+
+def test_split_points_cover_every_row_once():
+    from xdfm_amd.dist import split_points
+    for n in (1, 2, 7, 64, 150, 4097):
+        for w in (1, 2, 3, 8):
+            p = split_points(n, w)
+            assert p[0] == 0 and p[-1] == n and all(b >= a for a, b in zip(p, p[1:]))
+            assert max(b - a for a, b in zip(p, p[1:])) - min(b - a for a, b in zip(p, p[1:])) <= 1
+
+
+def test_row_parallel_fit_equals_single_process_cpu_gloo(tmp_path):
+    _check(tmp_path, "cpu", True, rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_row_parallel_fit_equals_single_process_gpu(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    _check(tmp_path, "cuda:0", False, rtol=1e-3, atol=2e-5)
