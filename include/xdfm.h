@@ -130,6 +130,28 @@ size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m);
 int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
                          int H, int Hp, int m, long N, float* ws, float* dW, void* stream);
 
+/* ------------------------------------------------------------------ attention pooling (K5)
+ * replaces: deepctr/layers/cin_attention.py:63-97 (MultiHeadSelfAttention), :130-144
+ *           (AttentionPooling) and the tails of CINAttention.forward :302-313 /
+ *           CINAttentionV2.forward :452-464: n_layers x (MHSA -> +residual -> LayerNorm) then
+ *           softmax_s(w2 . tanh(W1 x_s + b1)) weighted sum.  The [B,heads,S,S] score tensor of the
+ *           reference never exists; one workgroup handles one example with its S tokens on chip.
+ * fm     FM layout [S][B*D]: the concatenated direct-connect feature maps (tokens x_s = fm[s][b*D..]).
+ * theta  packed parameters: per layer Wq Wk Wv Wo ([D][D], nn.Linear weight layout), then gamma, beta
+ *        ([D] each, only if use_ln); then W1 [D][D], b1 [D], w2 [D]  (xdfm_cin_attn_theta_elems floats).
+ * nh     number of heads (must divide D; pairs (D, nh) are compiled for D in {4,8,10,16,32}).
+ * out    [B][D] pooled vector.  (CINAttention's output_proj D -> featuremap_num is a plain GEMM.)
+ * tok_save [n_layers][B][S][D], ml_save [n_layers][B][S][nh][2]: written by fwd, read by bwd.
+ * bwd: dout [B][D]; dfm [S][B*D] is overwritten; dtheta (same layout as theta) is ACCUMULATED into with
+ * fp32 atomics and must be zeroed by the caller.  S <= 1024.
+ */
+size_t xdfm_cin_attn_theta_elems(int D, int n_layers, int use_ln);
+int xdfm_cin_attn_pool_fwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
+                           const float* theta, float* out, float* tok_save, float* ml_save, void* stream);
+int xdfm_cin_attn_pool_bwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
+                           const float* theta, const float* tok_save, const float* ml_save, const float* dout,
+                           float* dfm, float* dtheta, void* stream);
+
 /* ------------------------------------------------------------------ L2 regulariser (K6)
  * replaces: deepctr/models/basemodel.py:412-428 (per-tensor square / mul / sum / add loop over
  *           ~58 tensors, every embedding table in full) and its autograd.

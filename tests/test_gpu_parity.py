@@ -367,3 +367,49 @@ def test_train_on_batch_matches_unfused_sequence():
     for k in grads[0]:
         gclose(grads[1][k], grads[0][k], k)
         gclose(grads[1][k], g["g:" + k], "vs reference " + k)
+
+
+@pytest.mark.parametrize("variant,B,m,D,ls,heads,ln,res,nl", [
+    ("attn", 5, 26, 16, (64, 48), 4, True, True, 1),       # S = 80
+    ("attn", 3, 7, 8, (40, 24), 4, False, True, 1),
+    ("attn_v2", 4, 22, 16, (48, 40), 2, True, False, 2),
+    ("attn", 2, 26, 16, (256, 128, 128), 4, True, True, 1),  # BASELINE config-3 token count S = 320
+    ("attn_v2", 3, 9, 32, (24, 20), 8, True, True, 1),
+    ("attn", 3, 6, 10, (12, 10), 4, True, True, 1),          # 10 % 4 != 0 -> 2 heads
+])
+def test_attention_kernel_vs_float64_oracle(variant, B, m, D, ls, heads, ln, res, nl):
+    """K5 forward/backward against the oracle evaluated in float64 (the attention gradients suffer
+    cancellation, so the yardstick is the exact value, with a tolerance scaled to each tensor)."""
+    from deepctr.layers import CINAttention, CINAttentionV2
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    torch.manual_seed(B + m + D)
+    if variant == "attn":
+        layer = CINAttention(m, D, ls, "relu", True, heads, 0.0, ln, res, 0.0, 1024, "cpu")
+    else:
+        layer = CINAttentionV2(m, D, ls, "relu", True, heads, 0.0, ln, res, nl, 0.0, 1024, "cpu")
+    with torch.no_grad():
+        for k, p in layer.named_parameters():
+            if "layer_norm" in k or k.endswith("attention.0.bias"):
+                p.add_(0.3 * torch.randn(p.shape))
+    x = torch.randn(B, m, D) * 0.7
+    spec = orc.Spec(["f%d" % i for i in range(m)], [1] * m, [], D, tuple(ls), True, "relu", (), variant, heads, ln,
+                    res, nl)
+    st64 = {"cin." + k: p.detach().double().requires_grad_(True) for k, p in layer.named_parameters()}
+    x64 = x.double().requires_grad_(True)
+    want = orc.cin_attention_forward(x64, st64, "cin.", spec)
+    gout = torch.randn(want.shape)
+    (want * gout.double()).sum().backward()
+    layer = layer.to(dev)
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg)
+    wn = want.detach().numpy()
+    close(out, wn, rtol=1e-4, atol=1e-5 * float(np.abs(wn).max()) + 1e-7, msg="out")
+    (out * gout.to(dev)).sum().backward()
+
+    def scaled(got, ref, name):
+        ref = ref.numpy()
+        close(got, ref, rtol=1e-3, atol=2e-4 * float(np.abs(ref).max()) + 1e-9, msg=name)
+    scaled(xg.grad, x64.grad, "dx")
+    for k, p in layer.named_parameters():
+        scaled(p.grad, st64["cin." + k].grad, k)

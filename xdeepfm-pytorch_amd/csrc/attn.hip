@@ -1,0 +1,705 @@
+// K5: attention pooling over the CIN feature maps, one workgroup per example, one thread per token.
+//
+// replaces deepctr/layers/cin_attention.py:63-97 (MultiHeadSelfAttention), :130-144
+// (AttentionPooling) and the tails of CINAttention.forward (:302-316: MHSA -> +residual ->
+// LayerNorm -> pooling -> output_proj) and CINAttentionV2.forward (:452-464: N x (MHSA, residual,
+// LayerNorm) -> pooling).  The reference materialises the [B, heads, S, S] score tensor (4.3-6.7 GB
+// at B=4096, S=256-320) forward and again for backward; here the S tokens of an example live in
+// LDS / registers and scores exist only as scalars.
+//
+// fp32 VALU on purpose: with head_dim 2-8 the contractions are tiny and the fp32 MFMA rate equals the
+// fp32 VALU rate on gfx950, so matrix cores would buy nothing; the cost is S^2*(3D FMA + heads exp).
+//
+// theta (all parameters, packed by the host): per layer  Wq Wk Wv Wo [D][D] each, then (use_ln)
+// gamma[D] beta[D];  after the layers  W1 [D][D], b1 [D], w2 [D].  The kernel returns the pooled
+// vector [B][D]; CINAttention's output_proj (D -> featuremap_num, cin_attention.py:316) is a plain
+// [B,D]x[D,fm] GEMM left to hipBLASLt like the model's other one-row heads.
+#include "xdfm_internal.h"
+
+template <int D>
+struct RowVec {   // widest aligned vector that divides a row of D floats
+    static constexpr int W = (D % 4 == 0) ? 4 : ((D % 2 == 0) ? 2 : 1);
+};
+
+template <int D>
+__device__ __forceinline__ void load_row(const float* __restrict__ p, float (&r)[D]) {
+    constexpr int W = RowVec<D>::W;
+    if constexpr (W == 4) {
+#pragma unroll
+        for (int c = 0; c < D / 4; ++c) {
+            const float4 v = reinterpret_cast<const float4*>(p)[c];
+            r[4 * c] = v.x; r[4 * c + 1] = v.y; r[4 * c + 2] = v.z; r[4 * c + 3] = v.w;
+        }
+    } else if constexpr (W == 2) {
+#pragma unroll
+        for (int c = 0; c < D / 2; ++c) {
+            const float2 v = reinterpret_cast<const float2*>(p)[c];
+            r[2 * c] = v.x; r[2 * c + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) r[c] = p[c];
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void store_row(float* __restrict__ p, const float (&r)[D]) {
+    constexpr int W = RowVec<D>::W;
+    if constexpr (W == 4) {
+#pragma unroll
+        for (int c = 0; c < D / 4; ++c)
+            reinterpret_cast<float4*>(p)[c] = make_float4(r[4 * c], r[4 * c + 1], r[4 * c + 2], r[4 * c + 3]);
+    } else if constexpr (W == 2) {
+#pragma unroll
+        for (int c = 0; c < D / 2; ++c) reinterpret_cast<float2*>(p)[c] = make_float2(r[2 * c], r[2 * c + 1]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) p[c] = r[c];
+    }
+}
+
+// y[i] += sum_d MT[d][i] * xrow[d]   (MT = transposed weight in LDS, xrow = this thread's row in LDS).
+// The loop over d stays rolled: x is indexed dynamically (from LDS), y statically (registers), and
+// only one weight row is live at a time -- a fully unrolled D x D matvec spills.
+template <int D>
+__device__ __forceinline__ void matvec_acc(const float* __restrict__ MT, const float* __restrict__ xrow, float (&y)[D]) {
+#pragma unroll 2
+    for (int d = 0; d < D; ++d) {
+        const float xd = xrow[d];
+        float w[D];
+        load_row<D>(MT + d * D, w);
+#pragma unroll
+        for (int i = 0; i < D; ++i) y[i] = fmaf(w[i], xd, y[i]);
+    }
+}
+
+// stage `nmat` [D][D] matrices transposed (dst[k][c][r] = src[k][r][c]) followed by `ntail` plain floats
+template <int D>
+__device__ __forceinline__ void stage_weights_t(float* __restrict__ dst, const float* __restrict__ src, int nmat,
+                                                int ntail) {
+    for (int i = threadIdx.x; i < nmat * D * D; i += blockDim.x) {
+        const int k = i / (D * D), rc = i - k * D * D, r = rc / D, c = rc - r * D;
+        dst[k * D * D + c * D + r] = src[i];
+    }
+    for (int i = threadIdx.x; i < ntail; i += blockDim.x) dst[nmat * D * D + i] = src[nmat * D * D + i];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// block-wide sum / max through a small LDS scratch (red has >= 16 floats); all threads get the result
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int k = 0; k < nw; ++k) t += red[k];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int k = 1; k < nw; ++k) t = fmaxf(t, red[k]);
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scores of one query against key row t, all heads
+template <int D, int NH>
+__device__ __forceinline__ void head_scores(const float (&q)[D], const float (&k)[D], float scale, float (&sc)[NH]) {
+    constexpr int HD = D / NH;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) a = fmaf(q[h * HD + e], k[h * HD + e], a);
+        sc[h] = a * scale;
+    }
+}
+
+// One MHSA layer for the token of this thread.  The token lives in the thread's row of Xs ([S][D+1],
+// padded pitch: every thread reads its own row) and is replaced there by the layer's output
+// (post residual / LayerNorm), which is also returned in a.  Ks/Vs: [S][D] LDS; WT: this layer's
+// weights in LDS, matrices transposed.  mx / ls: softmax statistics of the thread's query row.
+template <int D, int NH>
+__device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&mx)[NH], float (&ls)[NH], float* Xs, float* Ks,
+                                               float* Vs, const float* WT, int S, bool live, int use_ln,
+                                               int use_res) {
+    constexpr int HD = D / NH;
+    constexpr int XP = D + 1;
+    const int s = threadIdx.x;
+    float* xrow = Xs + s * XP;
+    const float scale = 1.0f / sqrtf((float)HD);
+    float q[D];
+    {
+        float kk[D], vv[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { q[i] = 0.f; kk[i] = 0.f; vv[i] = 0.f; }
+        matvec_acc<D>(WT, xrow, q);
+        matvec_acc<D>(WT + D * D, xrow, kk);
+        matvec_acc<D>(WT + 2 * D * D, xrow, vv);
+        if (live) {
+            store_row<D>(Ks + s * D, kk);
+            store_row<D>(Vs + s * D, vv);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < NH; ++h) { mx[h] = -3.0e38f; ls[h] = 0.f; }
+#pragma unroll 2
+    for (int t = 0; t < S; ++t) {                       // pass 1: row maxima (F.softmax subtracts them)
+        float k[D], sc[NH];
+        load_row<D>(Ks + t * D, k);
+        head_scores<D, NH>(q, k, scale, sc);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) mx[h] = fmaxf(mx[h], sc[h]);
+    }
+    float o[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[d] = 0.f;
+#pragma unroll 2
+    for (int t = 0; t < S; ++t) {                       // pass 2: exp, row sums, P.V
+        float k[D], v[D], sc[NH];
+        load_row<D>(Ks + t * D, k);
+        load_row<D>(Vs + t * D, v);
+        head_scores<D, NH>(q, k, scale, sc);
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const float p = __expf(sc[h] - mx[h]);
+            ls[h] += p;
+#pragma unroll
+            for (int e = 0; e < HD; ++e) o[h * HD + e] = fmaf(p, v[h * HD + e], o[h * HD + e]);
+        }
+    }
+    // a = (residual x) + W_o (o / l)
+#pragma unroll
+    for (int d = 0; d < D; ++d) a[d] = use_res ? xrow[d] : 0.f;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const float inv = 1.0f / ls[h];
+#pragma unroll
+        for (int e = 0; e < HD; ++e) xrow[h * HD + e] = o[h * HD + e] * inv;     // own row: no barrier needed
+    }
+    matvec_acc<D>(WT + 3 * D * D, xrow, a);
+    if (use_ln) {
+        const float* g = WT + 4 * D * D;
+        float mean = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) mean += a[d];
+        mean *= (1.0f / D);
+        float var = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) var = fmaf(a[d] - mean, a[d] - mean, var);
+        const float rstd = rsqrtf(var * (1.0f / D) + 1e-5f);
+#pragma unroll
+        for (int d = 0; d < D; ++d) a[d] = (a[d] - mean) * rstd * g[d] + g[D + d];
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) xrow[d] = a[d];
+}
+
+// TB = compile-time bound of the block size (round_up(S, 64) threads): 512 leaves 256 VGPRs per lane
+// (2 waves/SIMD), 1024 only 128 -- the host picks the smallest that covers S.
+template <int D, int NH, int TB>
+__global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
+    const float* __restrict__ fm, long N, int B, int S, int n_layers, int use_ln, int use_res,
+    const float* __restrict__ theta, float* __restrict__ out, float* __restrict__ tok_save,
+    float* __restrict__ ml_save) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int XP = D + 1;
+    float* Ks = smem;                                    // [S][D]
+    float* Vs = Ks + S * D;                              // [S][D]
+    float* Ws = Vs + S * D;                              // 4*D*D + 2*D floats (weights of the current stage)
+    float* red = Ws + 4 * D * D + 2 * D;                 // 16 + 16*D floats
+    float* Xs = red + 16 + 16 * D;                       // [blockDim][D+1] tokens, one row per thread
+    const int b = blockIdx.x;
+    const int s = threadIdx.x;
+    const bool live = s < S;
+    const int lsz = 4 * D * D + (use_ln ? 2 * D : 0);
+
+    float* xrow = Xs + s * XP;
+#pragma unroll
+    for (int d = 0; d < D; ++d) xrow[d] = live ? fm[(long)s * N + (long)b * D + d] : 0.f;
+
+    for (int layer = 0; layer < n_layers; ++layer) {
+        __syncthreads();                                 // previous layer's reads of Ks/Vs/Ws are done
+        stage_weights_t<D>(Ws, theta + (long)layer * lsz, 4, use_ln ? 2 * D : 0);
+        __syncthreads();
+        float a[D], mx[NH], ls[NH];
+        mhsa_layer_fwd<D, NH>(a, mx, ls, Xs, Ks, Vs, Ws, S, live, use_ln, use_res);
+        if (live) {
+            // saved for backward: the layer's output tokens and its softmax statistics (max, 1/sum)
+            store_row<D>(tok_save + (((long)layer * B + b) * S + s) * D, a);
+            float* ml = ml_save + ((((long)layer * B + b) * S + s) * NH) * 2;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) { ml[2 * h] = mx[h]; ml[2 * h + 1] = 1.0f / ls[h]; }
+        }
+    }
+
+    // attention pooling: softmax_s( w2 . tanh(W1 x_s + b1) ) weighted sum of the tokens
+    const float* tp = theta + (long)n_layers * lsz;
+    __syncthreads();
+    stage_weights_t<D>(Ws, tp, 1, 2 * D);                // W1^T, b1, w2
+    __syncthreads();
+    float x[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) x[d] = xrow[d];
+    float e = 0.f;
+    {
+        float u[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) u[i] = Ws[D * D + i];
+        matvec_acc<D>(Ws, xrow, u);
+#pragma unroll
+        for (int i = 0; i < D; ++i) e = fmaf(Ws[D * D + D + i], tanhf(u[i]), e);
+    }
+    const float emax = block_max(live ? e : -3.0e38f, red);
+    const float w = live ? __expf(e - emax) : 0.f;
+    const float wsum = block_sum(w, red);
+    const float alpha = w / wsum;
+    // pooled[d] = sum_s alpha_s x_s[d]: wave shuffle reduction, then across waves through LDS
+    float* pw = red + 16;
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float t = wave_sum(alpha * x[d]);
+        if ((threadIdx.x & 63) == 0) pw[wv * D + d] = t;
+    }
+    __syncthreads();
+    float* pooled = Ks;                                  // K/V are free now
+    if (threadIdx.x < D) {
+        float t = 0.f;
+        for (int k = 0; k < nw; ++k) t += pw[k * D + threadIdx.x];
+        pooled[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < D) out[(long)b * D + threadIdx.x] = pooled[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+static size_t attn_fwd_lds(int S, int D) {
+    return (size_t)(2 * S * D + 4 * D * D + 2 * D + 16 + 16 * D + round_up(S, 64) * (D + 1)) * sizeof(float);
+}
+
+template <int D, int NH>
+static int launch_attn_fwd(const float* fm, int B, int S, int n_layers, int use_ln, int use_res,
+                           const float* theta, float* out, float* tok_save, float* ml_save, hipStream_t st) {
+    const int threads = (int)round_up(S, 64);
+    const size_t lds = attn_fwd_lds(S, D);
+    if (threads <= 512)
+        hipLaunchKernelGGL((attn_pool_fwd_kernel<D, NH, 512>), dim3(B), dim3(threads), lds, st, fm, (long)B * D, B, S,
+                           n_layers, use_ln, use_res, theta, out, tok_save, ml_save);
+    else
+        hipLaunchKernelGGL((attn_pool_fwd_kernel<D, NH, 1024>), dim3(B), dim3(threads), lds, st, fm, (long)B * D, B, S,
+                           n_layers, use_ln, use_res, theta, out, tok_save, ml_save);
+    return xdfm_check_launch("cin_attn_pool_fwd");
+}
+
+#define ATTN_DISPATCH(FN, ...)                                                                  \
+    switch (D * 16 + nh) {                                                                      \
+        case 4 * 16 + 1: return FN<4, 1>(__VA_ARGS__);                                          \
+        case 4 * 16 + 2: return FN<4, 2>(__VA_ARGS__);                                          \
+        case 4 * 16 + 4: return FN<4, 4>(__VA_ARGS__);                                          \
+        case 8 * 16 + 1: return FN<8, 1>(__VA_ARGS__);                                          \
+        case 8 * 16 + 2: return FN<8, 2>(__VA_ARGS__);                                          \
+        case 8 * 16 + 4: return FN<8, 4>(__VA_ARGS__);                                          \
+        case 10 * 16 + 1: return FN<10, 1>(__VA_ARGS__);                                        \
+        case 10 * 16 + 2: return FN<10, 2>(__VA_ARGS__);                                        \
+        case 16 * 16 + 1: return FN<16, 1>(__VA_ARGS__);                                        \
+        case 16 * 16 + 2: return FN<16, 2>(__VA_ARGS__);                                        \
+        case 16 * 16 + 4: return FN<16, 4>(__VA_ARGS__);                                        \
+        case 16 * 16 + 8: return FN<16, 8>(__VA_ARGS__);                                        \
+        case 32 * 16 + 2: return FN<32, 2>(__VA_ARGS__);                                        \
+        case 32 * 16 + 4: return FN<32, 4>(__VA_ARGS__);                                        \
+        case 32 * 16 + 8: return FN<32, 8>(__VA_ARGS__);                                        \
+        default:                                                                                \
+            return xdfm_fail(XDFM_ERR_INVALID, "cin_attn_pool: (embedding_dim %d, heads %d) has no kernel instance", D, nh); \
+    }
+
+// =============================================================================================
+// backward
+// =============================================================================================
+// dst[i*D + d] += sum_s A[s][i] * Bm[s][d]   (A, Bm: [S][pitch] LDS tiles; dst: LDS accumulator)
+template <int D>
+__device__ __forceinline__ void outer_accumulate(float* __restrict__ dst, const float* __restrict__ A,
+                                                 const float* __restrict__ Bm, int pitch, int S) {
+    for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) {
+        const int i = idx / D, d = idx - i * D;
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) acc = fmaf(A[s * pitch + i], Bm[s * pitch + d], acc);
+        dst[idx] += acc;
+    }
+}
+
+// dst[d] += sum over the block of v[d] (wave shuffles, then one LDS atomic per wave and element)
+template <int D>
+__device__ __forceinline__ void vec_accumulate(float* __restrict__ dst, const float (&v)[D]) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float t = wave_sum(v[d]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&dst[d], t);
+    }
+}
+
+// LDS carve-up of the backward kernel (floats).  TP = rows of the per-thread tiles = blockDim.
+struct AttnBwdLds {
+    int kv, x, y, z, st, w, acc, red, total;
+};
+static __host__ __device__ inline AttnBwdLds attn_bwd_layout(int S, int D, int NH, int n_layers, int TP) {
+    AttnBwdLds L;
+    int off = 0;
+    L.kv = off;  off += 2 * S * D;                   // K,V  then Q,dO
+    L.x = off;   off += TP * (D + 1);                // tokens entering the stage (one row per thread)
+    L.y = off;   off += TP * (D + 1);                // scratch tile (o / do / dq ...)
+    L.z = off;   off += TP * (D + 1);                // scratch tile (dy / du / dk ...)
+    L.st = off;  off += S * 3 * NH;                  // per query: max, 1/sum, delta  per head
+    L.w = off;   off += 8 * D * D + 2 * D;           // transposed + plain weights of the stage
+    L.acc = off; off += n_layers * (4 * D * D + 2 * D) + D * D + 2 * D;   // parameter-gradient accumulator
+    L.red = off; off += 16 + 16 * D;
+    L.total = off;
+    return L;
+}
+
+template <int D, int NH, int TB>
+__global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
+    const float* __restrict__ fm, long N, int B, int S, int n_layers, int use_ln, int use_res,
+    const float* __restrict__ theta, const float* __restrict__ tok_save, const float* __restrict__ ml_save,
+    const float* __restrict__ dout, float* __restrict__ dfm, float* __restrict__ dtheta) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int HD = D / NH;
+    constexpr int XP = D + 1;
+    const AttnBwdLds L = attn_bwd_layout(S, D, NH, n_layers, blockDim.x);
+    float* Ks = smem + L.kv;
+    float* Vs = Ks + S * D;
+    float* Xs = smem + L.x;
+    float* Ys = smem + L.y;
+    float* Zs = smem + L.z;
+    float* St = smem + L.st;
+    float* WT = smem + L.w;                 // 4 transposed matrices (forward products)
+    float* WN = WT + 4 * D * D;             // 4 plain matrices (transposed products), then gamma/beta
+    float* Acc = smem + L.acc;
+    float* red = smem + L.red;
+    const int s = threadIdx.x;
+    const bool live = s < S;
+    const int lsz = 4 * D * D + (use_ln ? 2 * D : 0);
+    const int asz = n_layers * lsz + D * D + 2 * D;
+    const float scale = 1.0f / sqrtf((float)HD);
+    float* xrow = Xs + s * XP;
+    float* yrow = Ys + s * XP;
+    float* zrow = Zs + s * XP;
+
+    for (int i = threadIdx.x; i < asz; i += blockDim.x) Acc[i] = 0.f;
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        // ------------------------------------------------------------------ pooling backward
+        const float* tp = theta + (long)n_layers * lsz;
+        float* accp = Acc + n_layers * lsz;             // [dW1 (D*D) | db1 (D) | dw2 (D)]
+        __syncthreads();
+        stage_weights_t<D>(WT, tp, 1, 0);                                   // W1^T
+        for (int i = threadIdx.x; i < D * D + 2 * D; i += blockDim.x) WN[i] = tp[i];   // W1, b1, w2
+        {
+            const float* src = tok_save + (((long)(n_layers - 1) * B + b) * S + s) * D;
+            float x[D];
+            if (live) load_row<D>(src, x);
+#pragma unroll
+            for (int d = 0; d < D; ++d) xrow[d] = live ? x[d] : 0.f;
+        }
+        __syncthreads();
+        float da[D];                                     // gradient w.r.t. the tokens entering the pooling
+        {
+            float u[D], th[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) u[i] = WN[D * D + i];
+            matvec_acc<D>(WT, xrow, u);
+            float e = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) { th[i] = tanhf(u[i]); e = fmaf(WN[D * D + D + i], th[i], e); }
+            const float emax = block_max(live ? e : -3.0e38f, red);
+            const float w = live ? __expf(e - emax) : 0.f;
+            const float wsum = block_sum(w, red);
+            const float alpha = w / wsum;
+            float dpool[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) dpool[d] = dout[(long)b * D + d];
+            float dalpha = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) dalpha = fmaf(xrow[d], dpool[d], dalpha);
+            const float c = block_sum(alpha * dalpha, red);
+            const float de = alpha * (dalpha - c);       // softmax backward
+            float du[D], g2[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                g2[i] = de * th[i];                                         // d w2
+                du[i] = de * WN[D * D + D + i] * (1.f - th[i] * th[i]);      // through tanh
+                zrow[i] = du[i];
+            }
+            vec_accumulate<D>(accp + D * D + D, g2);
+            vec_accumulate<D>(accp + D * D, du);
+#pragma unroll
+            for (int d = 0; d < D; ++d) da[d] = alpha * dpool[d];
+            matvec_acc<D>(WN, zrow, da);                 // += W1^T du
+            __syncthreads();
+            outer_accumulate<D>(accp, Zs, Xs, XP, S);    // dW1[i][d] += sum_s du_s[i] x_s[d]
+        }
+
+        // ------------------------------------------------------------------ MHSA layers, last to first
+        for (int layer = n_layers - 1; layer >= 0; --layer) {
+            const float* th_l = theta + (long)layer * lsz;
+            float* accl = Acc + layer * lsz;             // [dWq | dWk | dWv | dWo | dgamma | dbeta]
+            __syncthreads();                             // previous stage done with Xs / Zs / weights
+            stage_weights_t<D>(WT, th_l, 4, 0);
+            for (int i = threadIdx.x; i < lsz; i += blockDim.x) WN[i] = th_l[i];
+            {
+                float x[D];
+                if (live) {
+                    if (layer == 0) {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) x[d] = fm[(long)s * N + (long)b * D + d];
+                    } else {
+                        load_row<D>(tok_save + (((long)(layer - 1) * B + b) * S + s) * D, x);
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) xrow[d] = live ? x[d] : 0.f;
+            }
+            float mx[NH], il[NH];
+            {
+                const float* ml = ml_save + ((((long)layer * B + b) * S + (live ? s : 0)) * NH) * 2;
+#pragma unroll
+                for (int h = 0; h < NH; ++h) { mx[h] = live ? ml[2 * h] : 0.f; il[h] = live ? ml[2 * h + 1] : 0.f; }
+            }
+            __syncthreads();
+            // recompute q, k, v and the attention output o
+            float q[D], kk[D], vv[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) { q[i] = 0.f; kk[i] = 0.f; vv[i] = 0.f; }
+            matvec_acc<D>(WT, xrow, q);
+            matvec_acc<D>(WT + D * D, xrow, kk);
+            matvec_acc<D>(WT + 2 * D * D, xrow, vv);
+            if (live) {
+                store_row<D>(Ks + s * D, kk);
+                store_row<D>(Vs + s * D, vv);
+            }
+            __syncthreads();
+            float o[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[d] = 0.f;
+#pragma unroll 2
+            for (int t = 0; t < S; ++t) {
+                float k[D], v[D], sc[NH];
+                load_row<D>(Ks + t * D, k);
+                load_row<D>(Vs + t * D, v);
+                head_scores<D, NH>(q, k, scale, sc);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const float p = __expf(sc[h] - mx[h]) * il[h];
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) o[h * HD + e] = fmaf(p, v[h * HD + e], o[h * HD + e]);
+                }
+            }
+            // y = W_o o (+x), LayerNorm backward -> dy
+            float dy[D];
+            {
+                float y[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) { y[d] = use_res ? xrow[d] : 0.f; yrow[d] = o[d]; }
+                matvec_acc<D>(WT + 3 * D * D, yrow, y);
+                if (use_ln) {
+                    const float* g = WN + 4 * D * D;
+                    float mean = 0.f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) mean += y[d];
+                    mean *= (1.0f / D);
+                    float var = 0.f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) var = fmaf(y[d] - mean, y[d] - mean, var);
+                    const float rstd = rsqrtf(var * (1.0f / D) + 1e-5f);
+                    float yh[D], dg[D], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        yh[d] = (y[d] - mean) * rstd;
+                        dg[d] = da[d] * yh[d];
+                        const float dyh = da[d] * g[d];
+                        m1 += dyh;
+                        m2 = fmaf(dyh, yh[d], m2);
+                    }
+                    m1 *= (1.0f / D);
+                    m2 *= (1.0f / D);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) dy[d] = rstd * (da[d] * g[d] - m1 - yh[d] * m2);
+                    vec_accumulate<D>(accl + 4 * D * D, dg);          // dgamma
+                    vec_accumulate<D>(accl + 4 * D * D + D, da);      // dbeta
+                } else {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) dy[d] = da[d];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) zrow[d] = dy[d];
+            __syncthreads();
+            outer_accumulate<D>(accl + 3 * D * D, Zs, Ys, XP, S);     // dWo[i][d] += sum_s dy_s[i] o_s[d]
+            // do = W_o^T dy ; delta_h = do_h . o_h ; dx starts as the residual branch
+            float dO[D], delta[NH], dx[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { dO[d] = 0.f; dx[d] = use_res ? dy[d] : 0.f; }
+            matvec_acc<D>(WN + 3 * D * D, zrow, dO);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) a = fmaf(dO[h * HD + e], o[h * HD + e], a);
+                delta[h] = a;
+            }
+            // pass A (thread = query): dq
+            float dq[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) dq[d] = 0.f;
+#pragma unroll 2
+            for (int t = 0; t < S; ++t) {
+                float k[D], v[D], sc[NH];
+                load_row<D>(Ks + t * D, k);
+                load_row<D>(Vs + t * D, v);
+                head_scores<D, NH>(q, k, scale, sc);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const float p = __expf(sc[h] - mx[h]) * il[h];
+                    float dp = 0.f;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) dp = fmaf(dO[h * HD + e], v[h * HD + e], dp);
+                    const float ds = p * (dp - delta[h]) * scale;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) dq[h * HD + e] = fmaf(ds, k[h * HD + e], dq[h * HD + e]);
+                }
+            }
+            __syncthreads();                             // all reads of K / V and of Ys / Zs are done
+            // stage Q, dO and the row statistics for the key-side pass (over the K / V storage)
+            float* Qs = Ks;
+            float* dOs = Vs;
+            if (live) {
+                store_row<D>(Qs + s * D, q);
+                store_row<D>(dOs + s * D, dO);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    St[(s * NH + h) * 3] = mx[h];
+                    St[(s * NH + h) * 3 + 1] = il[h];
+                    St[(s * NH + h) * 3 + 2] = delta[h];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) zrow[d] = dq[d];
+            __syncthreads();
+            outer_accumulate<D>(accl, Zs, Xs, XP, S);    // dWq[i][d] += sum_s dq_s[i] x_s[d]
+            matvec_acc<D>(WN, zrow, dx);                 // dx += Wq^T dq
+            // pass B (thread = key): dk, dv
+            float dk[D], dv[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+#pragma unroll 2
+            for (int r = 0; r < S; ++r) {
+                float qs[D], dos[D], sc[NH];
+                load_row<D>(Qs + r * D, qs);
+                load_row<D>(dOs + r * D, dos);
+                head_scores<D, NH>(qs, kk, scale, sc);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const float p = __expf(sc[h] - St[(r * NH + h) * 3]) * St[(r * NH + h) * 3 + 1];
+                    float dp = 0.f;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) dp = fmaf(dos[h * HD + e], vv[h * HD + e], dp);
+                    const float ds = p * (dp - St[(r * NH + h) * 3 + 2]) * scale;
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) {
+                        dv[h * HD + e] = fmaf(p, dos[h * HD + e], dv[h * HD + e]);
+                        dk[h * HD + e] = fmaf(ds, qs[h * HD + e], dk[h * HD + e]);
+                    }
+                }
+            }
+            if (!live) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+            }
+            __syncthreads();                             // outer_accumulate(dq) finished reading Zs
+#pragma unroll
+            for (int d = 0; d < D; ++d) zrow[d] = dk[d];
+            __syncthreads();
+            outer_accumulate<D>(accl + D * D, Zs, Xs, XP, S);          // dWk
+            matvec_acc<D>(WN + D * D, zrow, dx);                       // dx += Wk^T dk
+            __syncthreads();
+#pragma unroll
+            for (int d = 0; d < D; ++d) zrow[d] = dv[d];
+            __syncthreads();
+            outer_accumulate<D>(accl + 2 * D * D, Zs, Xs, XP, S);      // dWv
+            matvec_acc<D>(WN + 2 * D * D, zrow, dx);                   // dx += Wv^T dv
+            // dx is the gradient w.r.t. the tokens entering this layer
+            if (layer == 0) {
+                if (live) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) dfm[(long)s * N + (long)b * D + d] = dx[d];
+                }
+            } else {
+#pragma unroll
+                for (int d = 0; d < D; ++d) da[d] = dx[d];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < asz; i += blockDim.x) atomicAdd(&dtheta[i], Acc[i]);
+}
+
+template <int D, int NH>
+static int launch_attn_bwd(const float* fm, int B, int S, int n_layers, int use_ln, int use_res, const float* theta,
+                           const float* tok_save, const float* ml_save, const float* dout, float* dfm, float* dtheta,
+                           hipStream_t st) {
+    const int threads = (int)round_up(S, 64);
+    const size_t lds = (size_t)attn_bwd_layout(S, D, NH, n_layers, threads).total * sizeof(float);
+    if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_attn_pool_bwd: S=%d D=%d does not fit LDS", S, D);
+    const int grid = B < 1024 ? B : 1024;
+    if (threads <= 512)
+        hipLaunchKernelGGL((attn_pool_bwd_kernel<D, NH, 512>), dim3(grid), dim3(threads), lds, st, fm, (long)B * D, B, S,
+                           n_layers, use_ln, use_res, theta, tok_save, ml_save, dout, dfm, dtheta);
+    else
+        hipLaunchKernelGGL((attn_pool_bwd_kernel<D, NH, 1024>), dim3(grid), dim3(threads), lds, st, fm, (long)B * D, B, S,
+                           n_layers, use_ln, use_res, theta, tok_save, ml_save, dout, dfm, dtheta);
+    return xdfm_check_launch("cin_attn_pool_bwd");
+}
+
+extern "C" {
+
+size_t xdfm_cin_attn_theta_elems(int D, int n_layers, int use_ln) {
+    return (size_t)n_layers * (4 * D * D + (use_ln ? 2 * D : 0)) + (size_t)D * D + 2 * D;
+}
+
+int xdfm_cin_attn_pool_fwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
+                           const float* theta, float* out, float* tok_save, float* ml_save, void* stream) {
+    XDFM_REQUIRE(fm && theta && out && ml_save && tok_save, "cin_attn_pool_fwd: null pointer");
+    XDFM_REQUIRE(B > 0 && S > 0 && S <= 1024 && n_layers >= 1, "cin_attn_pool_fwd: bad shape B=%d S=%d layers=%d", B, S,
+                 n_layers);
+    XDFM_REQUIRE(attn_fwd_lds(S, D) <= 160 * 1024, "cin_attn_pool_fwd: S=%d D=%d does not fit LDS", S, D);
+    hipStream_t st = (hipStream_t)stream;
+    ATTN_DISPATCH(launch_attn_fwd, fm, B, S, n_layers, use_ln, use_res, theta, out, tok_save, ml_save, st)
+}
+
+int xdfm_cin_attn_pool_bwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
+                           const float* theta, const float* tok_save, const float* ml_save, const float* dout,
+                           float* dfm, float* dtheta, void* stream) {
+    XDFM_REQUIRE(fm && theta && tok_save && ml_save && dout && dfm && dtheta, "cin_attn_pool_bwd: null pointer");
+    XDFM_REQUIRE(B > 0 && S > 0 && S <= 1024 && n_layers >= 1, "cin_attn_pool_bwd: bad shape B=%d S=%d layers=%d", B, S,
+                 n_layers);
+    hipStream_t st = (hipStream_t)stream;
+    ATTN_DISPATCH(launch_attn_bwd, fm, B, S, n_layers, use_ln, use_res, theta, tok_save, ml_save, dout, dfm, dtheta, st)
+}
+
+}  // extern "C"

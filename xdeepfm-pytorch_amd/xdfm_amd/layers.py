@@ -157,14 +157,10 @@ class CINAttention(_CINBase):
         return self.forward_fm(ops.to_fm_layout(inputs), B, D)
 
     def forward_fm(self, x0_fm, B, D):
-        fm = self._levels(x0_fm, B, D, "fm")                  # [S, B*D]
-        tokens = ops.from_fm_layout(fm, B, D)                  # [B, S, D] view
-        a = self.mhsa(tokens)
-        if self.use_residual:
-            a = a + tokens
-        if self.use_layer_norm:
-            a = self.layer_norm(a)
-        return self.output_proj(self.attn_pooling(a))
+        fm = self._levels(x0_fm, B, D, "fm")                  # [S, B*D], FM layout
+        pooled = ops.attn_pool(fm, B, D, [self.mhsa], [self.layer_norm] if self.use_layer_norm else None,
+                               self.attn_pooling, self.use_residual)
+        return self.output_proj(pooled)
 
 
 class CINAttentionV2(_CINBase):
@@ -200,15 +196,10 @@ class CINAttentionV2(_CINBase):
         return self.forward_fm(ops.to_fm_layout(inputs), B, D)
 
     def forward_fm(self, x0_fm, B, D):
-        r = ops.from_fm_layout(self._levels(x0_fm, B, D, "fm"), B, D)
-        for i in range(self.num_attn_layers):
-            a = self.mhsa_layers[i](r)
-            if self.use_residual:
-                a = a + r
-            if self.use_layer_norm:
-                a = self.layer_norms[i](a)
-            r = a
-        return self.attn_pooling(r)
+        fm = self._levels(x0_fm, B, D, "fm")
+        return ops.attn_pool(fm, B, D, list(self.mhsa_layers),
+                             list(self.layer_norms) if self.use_layer_norm else None, self.attn_pooling,
+                             self.use_residual)
 
 
 class DNN(nn.Module):

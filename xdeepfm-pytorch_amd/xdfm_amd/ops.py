@@ -329,6 +329,75 @@ def from_fm_layout(t: torch.Tensor, B: int, D: int) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------------------------- #
+# attention pooling                                                                              #
+# --------------------------------------------------------------------------------------------- #
+class AttnPool(torch.autograd.Function):
+    """FM-layout feature maps [S, B*D] -> pooled [B, D] through n_layers x (MHSA, +residual, LayerNorm)
+    and the attention pooling (deepctr/layers/cin_attention.py:63-144, :302-313, :452-464).
+    params: per layer Wq, Wk, Wv, Wo (+ gamma, beta when use_ln), then W1, b1, w2."""
+
+    @staticmethod
+    def forward(ctx, fm, B, D, nh, n_layers, use_ln, use_res, *params):
+        _need_cuda(fm, "feature maps")
+        lib = _lib.load()
+        S = fm.shape[0]
+        assert fm.shape[1] == B * D and fm.is_contiguous()
+        theta = torch.cat([p.reshape(-1) for p in params])
+        assert theta.numel() == lib.xdfm_cin_attn_theta_elems(D, n_layers, int(use_ln))
+        dev = fm.device
+        out = torch.empty((B, D), dtype=torch.float32, device=dev)
+        tok = torch.empty((n_layers, B, S, D), dtype=torch.float32, device=dev)
+        ml = torch.empty((n_layers, B, S, nh, 2), dtype=torch.float32, device=dev)
+        # S^2 * (3 D FMA) per example and layer, counted as 2 FLOP per FMA
+        flops = 2.0 * 3 * D * S * S * B * n_layers
+        _lib.check(_run("cin_attn_pool_fwd", flops, lambda: lib.xdfm_cin_attn_pool_fwd(
+            _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(out), _ptr(tok), _ptr(ml),
+            _stream())), "cin_attn_pool_fwd")
+        ctx.cfg = (B, D, nh, n_layers, use_ln, use_res, [tuple(p.shape) for p in params])
+        ctx.save_for_backward(fm, theta, tok, ml)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        fm, theta, tok, ml = ctx.saved_tensors
+        B, D, nh, n_layers, use_ln, use_res, shapes = ctx.cfg
+        S = fm.shape[0]
+        dfm = torch.empty_like(fm)
+        dtheta = torch.zeros_like(theta)
+        dout = dout.contiguous()
+        flops = 2.0 * 7 * D * S * S * B * n_layers
+        _lib.check(_run("cin_attn_pool_bwd", flops, lambda: lib.xdfm_cin_attn_pool_bwd(
+            _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(tok), _ptr(ml), _ptr(dout),
+            _ptr(dfm), _ptr(dtheta), _stream())), "cin_attn_pool_bwd")
+        grads, off = [], 0
+        for sh in shapes:
+            n = 1
+            for k in sh:
+                n *= k
+            grads.append(dtheta[off:off + n].view(sh))
+            off += n
+        return (dfm, None, None, None, None, None, None) + tuple(grads)
+
+
+def attn_pool(fm, B, D, mhsa_layers, layer_norms, pooling, use_res):
+    """mhsa_layers: modules with W_q/W_k/W_v/W_o (nn.Linear, bias-free) and .num_heads; layer_norms:
+    matching nn.LayerNorm list or None; pooling: module whose .attention is Sequential(Linear, Tanh,
+    Linear(bias=False))."""
+    params = []
+    for l, att in enumerate(mhsa_layers):
+        params += [att.W_q.weight, att.W_k.weight, att.W_v.weight, att.W_o.weight]
+        if layer_norms is not None:
+            params += [layer_norms[l].weight, layer_norms[l].bias]
+        if att.dropout.p > 0 and att.training:
+            raise NotImplementedError("attention dropout > 0 is not implemented in the fused kernel "
+                                      "(the reference's scripts train with cin_attn_dropout = 0)")
+    params += [pooling.attention[0].weight, pooling.attention[0].bias, pooling.attention[2].weight]
+    nh = mhsa_layers[0].num_heads
+    return AttnPool.apply(fm, B, D, nh, len(mhsa_layers), layer_norms is not None, bool(use_res), *params)
+
+
+# --------------------------------------------------------------------------------------------- #
 # L2 regulariser                                                                                 #
 # --------------------------------------------------------------------------------------------- #
 class L2Plan:
