@@ -125,8 +125,9 @@ int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, co
                          int H, int Hp, int m, long N, float* dxp, float* dx0, void* stream);
 
 /* dW[h][i*m+j] = sum_n dOut[h][n] * x_prev[i][n] * x0[j][n]   (overwrites dW [H][Hp*m]).
- * ws: workspace of xdfm_cin_bwd_w_ws_elems floats. */
-size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m);
+ * ws: workspace of xdfm_cin_bwd_w_ws_elems floats (one partial copy of dW per n-split, summed in a
+ * fixed order: bitwise reproducible). */
+size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m, long N);
 int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
                          int H, int Hp, int m, long N, float* ws, float* dW, void* stream);
 

@@ -50,8 +50,9 @@ def test_workspace_size_queries():
     assert lib.xdfm_cin_fwd_pack_elems(512, 26, 22) == 2 * (288 + 4) * 64 * 8
     assert lib.xdfm_cin_bwd_pack_elems(128, 128, 26) == (4 * 26 * 16 + 3) * 256
     assert lib.xdfm_cin_bwd_pack_elems(300, 4, 4) == 0          # > 256 rows per call is rejected
-    assert lib.xdfm_cin_bwd_w_ws_elems(128, 64, 26) == 26 * 128 * 64
-    assert lib.xdfm_cin_bwd_w_ws_elems(6, 5, 3) == 3 * 32 * 32
+    # one dWt copy per n-split: (L2 of config 2: 7 workgroups per split -> 73 splits of 928 columns)
+    assert lib.xdfm_cin_bwd_w_ws_elems(128, 64, 26, 65536) == 26 * 128 * 64 * 71
+    assert lib.xdfm_cin_bwd_w_ws_elems(6, 5, 3, 40) == 3 * 32 * 32 * 2
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -6,10 +6,11 @@ static thread_local char g_err[512] = "";
 static int g_opts[OPT_COUNT] = {
     /* OPT_FWD_NF */ 1,
     /* OPT_BWW_NSPLIT */ 0,
-    /* OPT_BWW_SLAB */ 0,
+    /* OPT_BWW_SLAB */ 1,
+    /* OPT_BWW_MT */ 0,
     /* OPT_DBG */ 0,
 };
-static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "dbg"};
+static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg"};
 
 int xdfm_fail(int code, const char* fmt, ...) {
     va_list ap;

@@ -13,32 +13,60 @@
 // =============================================================================================
 // dOut + dbias
 // =============================================================================================
+// VEC = 4: N % 4 == 0 and D % 4 == 0, so a float4 never straddles two examples and every row is
+// 16-byte aligned; VEC = 1 is the generic path.  One block = one row h x 1024*VEC.. columns.
+template <int VEC>
 __global__ __launch_bounds__(256) void cin_dout_kernel(
     const float* __restrict__ A, int H, long N, int D, int act,
     const float* __restrict__ dHid, int hid0, int hid_rows,
     const float* __restrict__ dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
     float* __restrict__ dOut, float* __restrict__ dbias) {
     const int h = blockIdx.y;
-    const long nbase = (long)blockIdx.x * 1024;
     const bool has_hid = dHid && h >= hid0 && h < hid0 + hid_rows;
     const bool has_dir = dDir && h >= dir0 && h < dir0 + dir_rows;
+    const float* __restrict__ arow = A + (long)h * N;
+    const float* __restrict__ hrow = has_hid ? dHid + (long)(h - hid0) * N : nullptr;
+    const float* __restrict__ drow = (has_dir && dir_mode == 1) ? dDir + (long)(dir_off + h - dir0) * N : nullptr;
+    const float* __restrict__ dres = (has_dir && dir_mode == 0) ? dDir + dir_off + (h - dir0) : nullptr;
+    float* __restrict__ orow = dOut + (long)h * N;
     float part = 0.f;
+    const long base = (long)blockIdx.x * (1024 * VEC);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const long n = nbase + k * 256 + threadIdx.x;
+        const long n = base + ((long)k * 256 + threadIdx.x) * VEC;
         if (n < N) {
-            float g = 0.f;
-            if (has_hid) g += dHid[(long)(h - hid0) * N + n];
-            if (has_dir) {
-                if (dir_mode == 0) g += dDir[(n / D) * lddir + dir_off + (h - dir0)];
-                else g += dDir[(long)(dir_off + h - dir0) * N + n];
+            float g[VEC], a[VEC];
+            if constexpr (VEC == 4) {
+                const float4 av = *reinterpret_cast<const float4*>(arow + n);
+                a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+                g[0] = g[1] = g[2] = g[3] = 0.f;
+                if (hrow) {
+                    const float4 hv = *reinterpret_cast<const float4*>(hrow + n);
+                    g[0] = hv.x; g[1] = hv.y; g[2] = hv.z; g[3] = hv.w;
+                }
+                if (drow) {
+                    const float4 dv = *reinterpret_cast<const float4*>(drow + n);
+                    g[0] += dv.x; g[1] += dv.y; g[2] += dv.z; g[3] += dv.w;
+                }
+                if (dres) {
+                    const float r = dres[(n / D) * lddir];       // the 4 columns belong to one example
+                    g[0] += r; g[1] += r; g[2] += r; g[3] += r;
+                }
+            } else {
+                a[0] = arow[n];
+                g[0] = hrow ? hrow[n] : 0.f;
+                if (drow) g[0] += drow[n];
+                if (dres) g[0] += dres[(n / D) * lddir];
             }
-            if (act == XDFM_ACT_RELU && !(A[(long)h * N + n] > 0.f)) g = 0.f;
-            dOut[(long)h * N + n] = g;
-            part += g;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (act == XDFM_ACT_RELU && !(a[e] > 0.f)) g[e] = 0.f;
+                part += g[e];
+            }
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(orow + n) = make_float4(g[0], g[1], g[2], g[3]);
+            else orow[n] = g[0];
         }
     }
-    // block reduction -> one atomic per block
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     __shared__ float wsum[4];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
@@ -286,7 +314,7 @@ template <int MT, int JT>
 __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
     const float* __restrict__ dOut, const float* __restrict__ xp, const float* __restrict__ x0,
     int H, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad, int IPAD,
-    float* __restrict__ dWt) {
+    float* __restrict__ dWt, long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     static_assert(JT == 2, "one DMA instruction stages exactly two x0 rows");
     const int tid = threadIdx.x;
@@ -315,23 +343,24 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
     const float* src0 = x0 + (long)(j_own < m ? j_own : m - 1) * N;
     const int drow0 = wave * (DROWS / 4);               // first dOut row (within the h-group) of this wave
 
-    auto issue = [&](long nc0, int buf) {
+    // DMA instruction `k` (0 .. NDMA-1) of the chunk starting at column nc0 into buffer `buf`
+    auto dma_k = [&](int k, long nc0, int buf) {
         float* base = smem + buf * BUF;
-#pragma unroll
-        for (int k = 0; k < DROWS / 8; ++k) {
+        if (k < DROWS / 8) {
             const int row = drow0 + 2 * k + s;
             int h = hg * DROWS + row;
             h = h < H ? h : H - 1;
             dma_dword(dOut + (long)h * N + nc0 + (c ^ (row & 31)), base + (drow0 + 2 * k) * 32);
-        }
-        float* wb = base + DROWS * 32 + wave * (WROWS * 32);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            int i = iblk * 32 + 2 * k + s;
+        } else if (k < DROWS / 8 + 16) {
+            const int kk = k - DROWS / 8;
+            float* wb = base + DROWS * 32 + wave * (WROWS * 32);
+            int i = iblk * 32 + 2 * kk + s;
             i = i < Hp ? i : Hp - 1;
-            dma_dword(xp + (long)i * N + nc0 + (c ^ (2 * k + s)), wb + (2 * k) * 32);
+            dma_dword(xp + (long)i * N + nc0 + (c ^ (2 * kk + s)), wb + (2 * kk) * 32);
+        } else {
+            float* wb = base + DROWS * 32 + wave * (WROWS * 32);
+            dma_dword(src0 + nc0 + (c ^ s), wb + 32 * 32);
         }
-        dma_dword(src0 + nc0 + (c ^ s), wb + 32 * 32);
     };
 
     f32x16 acc[MT][JT];
@@ -342,12 +371,17 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][jt][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    // k-steps of one chunk; when `next` >= 0 the DMA instructions of the following chunk are issued
+    // in the shadow of the MFMAs (a few per k-step) instead of in a separate phase
+    constexpr int KSTEPS = BWW_NC / 2;
+    constexpr int DPS = (NDMA + KSTEPS - 1) / KSTEPS;   // DMA instructions per k-step
+    auto compute = [&](int buf, long next_nc0, int next_buf) {
         const float* dS = smem + buf * BUF;
         const float* xS = dS + DROWS * 32 + wave * (WROWS * 32);
         const float* zS = xS + 32 * 32;
-#pragma unroll 4
-        for (int t = 0; t < BWW_NC / 2; ++t) {
+        const bool has_next = next_nc0 >= 0;
+#pragma unroll
+        for (int t = 0; t < KSTEPS; ++t) {
             const int col = 2 * t + s;
             float a[MT], b[JT];
 #pragma unroll
@@ -355,6 +389,11 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
             const float xv = xS[c * 32 + (col ^ c)];
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) b[jt] = xv * zS[jt * 32 + (col ^ jt)];
+            if (has_next) {
+#pragma unroll
+                for (int q = 0; q < DPS; ++q)
+                    if (t * DPS + q < NDMA) dma_k(t * DPS + q, next_nc0, next_buf);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -363,17 +402,19 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
         }
     };
 
-    if (nfull > 0) issue(n_begin, 0);
-    for (int ch = 0; ch < nfull; ++ch) {
-        if (ch + 1 < nfull) {
-            issue(n_begin + (long)(ch + 1) * BWW_NC, (ch + 1) & 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");   // chunk ch landed, ch+1 in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) dma_k(k, n_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        compute(ch & 1);
-        __builtin_amdgcn_s_barrier();          // everyone is done with buf[ch&1] before it is refilled
+    }
+    for (int ch = 0; ch < nfull; ++ch) {
+        const long nxt = (ch + 1 < nfull) ? n_begin + (long)(ch + 1) * BWW_NC : -1;
+        compute(ch & 1, nxt, (ch + 1) & 1);
+        // one barrier per chunk: chunk ch+1 has landed everywhere AND everyone has finished reading
+        // buf[ch&1], which the DMA issued during compute(ch+1) will overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
     // tail chunk with fewer than 32 valid columns: masked register staging into buffer 0
     const long nt0 = n_begin + (long)nfull * BWW_NC;
@@ -397,11 +438,14 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
         }
         wb[(32 + s) * 32 + (c ^ s)] = src0[ncl] * ((j_own < m) ? cm : 0.f);
         __syncthreads();
-        compute(0);
+        compute(0, -1, 0);
     }
 
     if (!active) return;
     const int i = iblk * 32 + c;
+    // slab mode: this n-split owns a private copy of dWt (plain 128-B row-segment stores, summed in a
+    // fixed order by the unpack kernel: deterministic); otherwise fp32 atomics into one copy
+    float* __restrict__ dst = dWt + (long)blockIdx.y * slab_stride;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -410,27 +454,38 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int h = hg * 32 * MT + mt * 32 + frag_row(r, s);
-                if (h < H && i < Hp && j < m)
-                    atomicAdd(&dWt[((long)j * Hpad + h) * IPAD + i], acc[mt][jt][r]);
+                if (h < H && i < Hp && j < m) {
+                    if (slab_stride) dst[((long)j * Hpad + h) * IPAD + i] = acc[mt][jt][r];
+                    else atomicAdd(&dst[((long)j * Hpad + h) * IPAD + i], acc[mt][jt][r]);
+                }
             }
         }
 }
 
-__global__ void cin_bwd_w_unpack_kernel(const float* __restrict__ dWt, int H, int Hp, int m, int Hpad,
-                                        int IPAD, float* __restrict__ dW) {
-    const long K = (long)Hp * m;
+// dW[h][i*m+j] = sum over n-splits of dWt[split][j][h][i]; threads walk the dWt layout (i fastest) so
+// the slab reads are coalesced.
+__global__ void cin_bwd_w_unpack_kernel(const float* __restrict__ dWt, int H, int Hp, int m, int Hpad, int IPAD,
+                                        int nslab, long slab_stride, float* __restrict__ dW) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)H * K) return;
-    const int h = (int)(idx / K);
-    const long k = idx - (long)h * K;
-    const int i = (int)(k / m), j = (int)(k - (long)i * m);
-    dW[idx] = dWt[((long)j * Hpad + h) * IPAD + i];
+    const long total = (long)m * Hpad * IPAD;
+    if (idx >= total) return;
+    const int i = (int)(idx % IPAD);
+    const long jh = idx / IPAD;
+    const int h = (int)(jh % Hpad), j = (int)(jh / Hpad);
+    if (i >= Hp || h >= H) return;
+    float acc = 0.f;
+    for (int k = 0; k < nslab; ++k) acc += dWt[(long)k * slab_stride + idx];
+    dW[(long)h * ((long)Hp * m) + (long)i * m + j] = acc;
 }
 
 // =============================================================================================
 // host side
 // =============================================================================================
-static inline int bww_mt(int H) { return H > 64 ? 4 : (H > 32 ? 2 : 1); }
+static inline int bww_mt(int H) {
+    const int o = xdfm_opt(OPT_BWW_MT);
+    if (o == 1 || o == 2 || o == 4) return o;
+    return H > 64 ? 4 : (H > 32 ? 2 : 1);
+}
 #define BWW_JT 2
 
 template <int HS4>
@@ -445,43 +500,58 @@ static int launch_bwd_x(const float* dOut, const float* xp, const float* x0, con
     return xdfm_check_launch("cin_level_bwd_x");
 }
 
+struct BwwGeom {
+    int MT, IB, JP, TPH, HG, Hpad, IPAD, gx, nsplit;
+    long n_per_split, slab;        // slab = elements of one dWt copy
+};
+static BwwGeom bww_geometry(int H, int Hp, int m, long N) {
+    BwwGeom g;
+    g.MT = bww_mt(H);
+    g.IB = ceil_div(Hp, 32);
+    g.JP = ceil_div(m, BWW_JT);
+    g.TPH = (int)round_up((long)g.JP * g.IB, 4);
+    g.HG = ceil_div(H, 32 * g.MT);
+    g.Hpad = g.HG * 32 * g.MT;
+    g.IPAD = g.IB * 32;
+    g.gx = g.HG * g.TPH / 4;
+    int nsplit = xdfm_opt(OPT_BWW_NSPLIT);
+    const int max_split = ceil_div(N, BWW_NC);
+    // default: one resident round -- 2 workgroups per CU (LDS / VGPR limit) x 256 CUs.  More splits
+    // only add reduction traffic and a ragged last round (1027 workgroups on 512 slots ran 3 rounds).
+    if (nsplit <= 0) nsplit = 512 / g.gx > 0 ? 512 / g.gx : 1;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > 65535) nsplit = 65535;
+    g.n_per_split = round_up(ceil_div(N, nsplit), BWW_NC);
+    g.nsplit = ceil_div(N, g.n_per_split);
+    g.slab = (long)m * g.Hpad * g.IPAD;
+    return g;
+}
+
 template <int MT>
 static int launch_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,
                         float* ws, float* dW, hipStream_t st) {
     constexpr int JT = BWW_JT;
-    const int IB = ceil_div(Hp, 32);
-    const int JP = ceil_div(m, JT);
-    const int TPH = (int)round_up((long)JP * IB, 4);
-    const int HG = ceil_div(H, 32 * MT);
-    const int Hpad = HG * 32 * MT;
-    const int IPAD = IB * 32;
-    const int gx = HG * TPH / 4;
-    int nsplit = xdfm_opt(OPT_BWW_NSPLIT);
-    const int max_split = ceil_div(N, BWW_NC);
-    // default: one resident round -- 2 workgroups per CU (LDS / VGPR limit) x 256 CUs.  More splits
-    // only add atomic traffic and a ragged last round (1027 workgroups on 512 slots ran 3 rounds).
-    if (nsplit <= 0) nsplit = 512 / gx > 0 ? 512 / gx : 1;
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit > 65535) nsplit = 65535;
-    const long n_per_split = round_up(ceil_div(N, nsplit), BWW_NC);
-    nsplit = ceil_div(N, n_per_split);
-    const size_t ws_bytes = (size_t)m * Hpad * IPAD * sizeof(float);
-    hipError_t e = hipMemsetAsync(ws, 0, ws_bytes, st);
-    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_level_bwd_w memset: %s", hipGetErrorString(e));
-    if (xdfm_opt(OPT_DBG) & 8) {      // v1: register staging, single LDS buffer
+    const BwwGeom g = bww_geometry(H, Hp, m, N);
+    const bool slab = xdfm_opt(OPT_BWW_SLAB) != 0;
+    if (!slab) {
+        hipError_t e = hipMemsetAsync(ws, 0, (size_t)g.slab * sizeof(float), st);
+        if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_level_bwd_w memset: %s", hipGetErrorString(e));
+    }
+    const long stride = slab ? g.slab : 0;
+    if (xdfm_opt(OPT_DBG) & 8) {      // v1: register staging, single LDS buffer (atomics only)
+        if (slab) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_w: dbg 8 needs bww_slab=0");
         const size_t lds = (size_t)(32 * MT + 4 * (32 + JT)) * BWW_PITCH * sizeof(float);
-        hipLaunchKernelGGL((cin_bwd_w_kernel<MT, JT>), dim3(gx, nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp, m,
-                           N, IB, JP, TPH, n_per_split, Hpad, IPAD, ws);
+        hipLaunchKernelGGL((cin_bwd_w_kernel<MT, JT>), dim3(g.gx, g.nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp, m,
+                           N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, ws);
     } else {
         const size_t lds = (size_t)2 * (32 * MT + 4 * (32 + JT)) * 32 * sizeof(float);
-        hipLaunchKernelGGL((cin_bwd_w_dma_kernel<MT, JT>), dim3(gx, nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp,
-                           m, N, IB, JP, TPH, n_per_split, Hpad, IPAD, ws);
+        hipLaunchKernelGGL((cin_bwd_w_dma_kernel<MT, JT>), dim3(g.gx, g.nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp,
+                           m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, ws, stride);
     }
     int rc = xdfm_check_launch("cin_level_bwd_w");
     if (rc) return rc;
-    const long total = (long)H * Hp * m;
-    hipLaunchKernelGGL(cin_bwd_w_unpack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, ws, H, Hp, m, Hpad,
-                       IPAD, dW);
+    hipLaunchKernelGGL(cin_bwd_w_unpack_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, ws, H, Hp, m, g.Hpad,
+                       g.IPAD, slab ? g.nsplit : 1, stride, dW);
     return xdfm_check_launch("cin_level_bwd_w unpack");
 }
 
@@ -497,9 +567,15 @@ int xdfm_cin_dout(const float* A, int H, int B, int D, int act, const float* dHi
                      dir0 + dir_rows <= H, "cin_dout: row ranges outside [0,%d)", H);
     XDFM_REQUIRE(dir_mode == 0 || dir_mode == 1, "cin_dout: dir_mode %d", dir_mode);
     const long N = (long)B * D;
-    hipLaunchKernelGGL(cin_dout_kernel, dim3(ceil_div(N, 1024), H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
-                       act, hid_rows > 0 ? dHid : nullptr, hid0, hid_rows, dir_rows > 0 ? dDir : nullptr, dir_mode,
-                       lddir, dir_off, dir0, dir_rows, dOut, dbias);
+    const float* dh = hid_rows > 0 ? dHid : nullptr;
+    const float* dd = dir_rows > 0 ? dDir : nullptr;
+    const bool vec = (N % 4 == 0) && (D % 4 == 0) && ((((size_t)A) | ((size_t)dOut) | ((size_t)dh) | ((size_t)dd)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(cin_dout_kernel<4>, dim3(ceil_div(N, 4096), H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
+                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias);
+    else
+        hipLaunchKernelGGL(cin_dout_kernel<1>, dim3(ceil_div(N, 1024), H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
+                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias);
     return xdfm_check_launch("cin_dout");
 }
 
@@ -535,10 +611,10 @@ int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, co
     }
 }
 
-size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m) {
-    if (H <= 0 || Hp <= 0 || m <= 0) return 0;
-    const int MT = bww_mt(H);
-    return (size_t)m * (size_t)(ceil_div(H, 32 * MT) * 32 * MT) * (size_t)(ceil_div(Hp, 32) * 32);
+size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m, long N) {
+    if (H <= 0 || Hp <= 0 || m <= 0 || N <= 0) return 0;
+    const BwwGeom g = bww_geometry(H, Hp, m, N);
+    return (size_t)g.slab * (size_t)(xdfm_opt(OPT_BWW_SLAB) ? g.nsplit : 1);
 }
 
 int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,

@@ -191,7 +191,8 @@ struct RingSize {   // smallest R >= 4 such that slot(u) = u % R never collides 
 template <int MT, int NF, int MPT>
 __global__ __launch_bounds__(256, 2) void cin_fwd_mp_kernel(
     const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ Wf,
-    const float* __restrict__ bias, int H, int Hp, int m, long N, int TP, int act, float* __restrict__ out) {
+    const float* __restrict__ bias, int H, int Hp, int m, long N, int TP, int act, float* __restrict__ out,
+    int dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void cin_fwd_mp_kernel(
     const int mb = blockIdx.y;
     constexpr int WC = 32 * NF;
     constexpr int R = RingSize<MPT>::value;
+    const int wstep = (dbg & 1) ? 0 : MPT * 64 * MT;     // timing experiment: re-read one cached slab
     constexpr int RP = 64 / WC;
 
     float* xps = smem + wave * (FWD_IC * WC);
@@ -252,26 +254,53 @@ __global__ __launch_bounds__(256, 2) void cin_fwd_mp_kernel(
         const int cnt = (Hp - i0 < FWD_IC) ? Hp - i0 : FWD_IC;
         const float* wpi = wp + (long)i0 * (MPT * 64 * MT);
         const float* xl = xps + c;
-        for (int il = 0; il < cnt; ++il) {
-            float xv[NF];
+        float xv[NF];
 #pragma unroll
-            for (int f = 0; f < NF; ++f) xv[f] = xl[f * 32];
+        for (int f = 0; f < NF; ++f) xv[f] = xl[f * 32];
+        float b[NF];                                     // B operand of the NEXT k-step, formed one step early
+#pragma unroll
+        for (int f = 0; f < NF; ++f) b[f] = xv[f] * x0r[f][0];
+        // One i = MPT straight-line k-steps.  hipcc drains vmcnt(0) at a loop header whose back edge
+        // carries in-flight loads (one L2 round trip per iteration), so the loop over i is unrolled by
+        // hand to make iterations 4 x MPT k-steps long.
+        auto one_i = [&](int il) {
+            float xn[NF];                                // x_prev of the next i (clamped inside the chunk)
+            const int iln = (il + 1 < cnt) ? il + 1 : il;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) xn[f] = xps[iln * WC + f * 32 + c];
 #pragma unroll
             for (int u = 0; u < MPT; ++u) {
                 load_afrag<MT>(wpi + (u + FWD_PD) * (64 * MT), a[(u + FWD_PD) % MPT % R]);
-                float b[NF];
+                float bcur[NF];
 #pragma unroll
-                for (int f = 0; f < NF; ++f) b[f] = xv[f] * x0r[f][u];
+                for (int f = 0; f < NF; ++f) bcur[f] = b[f];
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                     for (int f = 0; f < NF; ++f)
-                        acc[mt][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u % R][mt], b[f], acc[mt][f], 0, 0, 0);
+                        acc[mt][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u % R][mt], bcur[f], acc[mt][f], 0, 0, 0);
+                    if (mt == 0) {
+                        // one v_mul in the shadow of the first MFMA: the next step's operand is ready
+                        // long before its MFMAs issue (no VALU -> MFMA read stall at the step boundary)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+                            b[f] = (u + 1 < MPT) ? xv[f] * x0r[f][(u + 1) % MPT] : xn[f] * x0r[f][0];
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);   // keep the prefetch distance hipcc would otherwise collapse
             }
-            wpi += MPT * 64 * MT;
-            xl += WC;
+#pragma unroll
+            for (int f = 0; f < NF; ++f) xv[f] = xn[f];
+            wpi += wstep;
+        };
+        int il = 0;
+        for (; il + 4 <= cnt; il += 4) {
+            one_i(il);
+            one_i(il + 1);
+            one_i(il + 2);
+            one_i(il + 3);
         }
+        for (; il < cnt; ++il) one_i(il);
     }
 
 #pragma unroll
@@ -338,7 +367,7 @@ static int launch_fwd_mp(const float* xp, const float* x0, const float* Wf, cons
     if (xdfm_opt(OPT_DBG) & 4) lds = 80 * 1024;
     dim3 grid(ceil_div(N, 128L * NF), MB);
     hipLaunchKernelGGL((cin_fwd_mp_kernel<MT, NF, MPT>), grid, dim3(256), lds, st, xp, x0, Wf, bias, H, Hp, m, N, TP,
-                       act, out);
+                       act, out, xdfm_opt(OPT_DBG));
     return xdfm_check_launch("cin_level_fwd");
 }
 

@@ -22,12 +22,15 @@ __global__ __launch_bounds__(REG_THREADS) void l2_sumsq_kernel(const float* cons
     const long n = numel[t];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     const long stride = (long)REG_BLOCKS * REG_THREADS;
-    long i = (long)blockIdx.x * REG_THREADS + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const float v0 = w[i], v1 = w[i + stride], v2 = w[i + 2 * stride], v3 = w[i + 3 * stride];
-        a0 = fmaf(v0, v0, a0); a1 = fmaf(v1, v1, a1); a2 = fmaf(v2, v2, a2); a3 = fmaf(v3, v3, a3);
+    const long tid = (long)blockIdx.x * REG_THREADS + threadIdx.x;
+    const bool vec = (((size_t)w) & 15) == 0;
+    const long n4 = vec ? n / 4 : 0;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w);
+    for (long i = tid; i < n4; i += stride) {
+        const float4 v = w4[i];
+        a0 = fmaf(v.x, v.x, a0); a1 = fmaf(v.y, v.y, a1); a2 = fmaf(v.z, v.z, a2); a3 = fmaf(v.w, v.w, a3);
     }
-    for (; i < n; i += stride) { const float v = w[i]; a0 = fmaf(v, v, a0); }
+    for (long i = 4 * n4 + tid; i < n; i += stride) { const float v = w[i]; a0 = fmaf(v, v, a0); }
     float part = (a0 + a1) + (a2 + a3);
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     __shared__ float wsum[REG_THREADS / 64];
@@ -67,9 +70,25 @@ __global__ __launch_bounds__(REG_THREADS) void l2_grad_kernel(const float* const
     float* __restrict__ g = gflat + goff[t];
     const long n = numel[t];
     const float sc = 2.f * coeff[t] * gscale[0];
-    const long stride = (long)gridDim.x * REG_THREADS;
-    for (long i = (long)blockIdx.x * REG_THREADS + threadIdx.x; i < n; i += stride)
-        g[i] = accumulate ? fmaf(sc, w[i], g[i]) : sc * w[i];
+    const long tid = (long)blockIdx.x * REG_THREADS + threadIdx.x;
+    const long nthr = (long)gridDim.x * REG_THREADS;
+    // 16-byte path when both streams are aligned (embedding tables are); scalar tail / fallback
+    const bool vec = ((((size_t)w) | ((size_t)g)) & 15) == 0;
+    const long n4 = vec ? n / 4 : 0;
+    const float4* __restrict__ w4 = reinterpret_cast<const float4*>(w);
+    float4* __restrict__ g4 = reinterpret_cast<float4*>(g);
+    for (long i = tid; i < n4; i += nthr) {
+        const float4 v = w4[i];
+        float4 r;
+        if (accumulate) {
+            r = g4[i];
+            r.x = fmaf(sc, v.x, r.x); r.y = fmaf(sc, v.y, r.y); r.z = fmaf(sc, v.z, r.z); r.w = fmaf(sc, v.w, r.w);
+        } else {
+            r = make_float4(sc * v.x, sc * v.y, sc * v.z, sc * v.w);
+        }
+        g4[i] = r;
+    }
+    for (long i = 4 * n4 + tid; i < n; i += nthr) g[i] = accumulate ? fmaf(sc, w[i], g[i]) : sc * w[i];
 }
 
 extern "C" {
@@ -90,8 +109,8 @@ int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* co
                     float* gflat, const long* goff, int accumulate, void* stream) {
     XDFM_REQUIRE(ptrs && numel && coeff && gscale && gflat && goff, "l2_reg_bwd: null pointer");
     XDFM_REQUIRE(T > 0 && T <= 65535, "l2_reg_bwd: T=%d", T);
-    hipLaunchKernelGGL(l2_grad_kernel, dim3(REG_BLOCKS, T), dim3(REG_THREADS), 0, (hipStream_t)stream, ptrs, numel,
-                       coeff, gscale, gflat, goff, accumulate);
+    hipLaunchKernelGGL(l2_grad_kernel, dim3(4 * REG_BLOCKS, T), dim3(REG_THREADS), 0, (hipStream_t)stream, ptrs,
+                       numel, coeff, gscale, gflat, goff, accumulate);
     return xdfm_check_launch("l2_reg_bwd");
 }
 

@@ -16,7 +16,8 @@ int xdfm_opt(int idx);
 enum {
     OPT_FWD_NF = 0,      // column fragments (32 cols each) per wave in the forward kernel: 1 or 2
     OPT_BWW_NSPLIT,      // 0 = auto; n-range splits of the dW kernel
-    OPT_BWW_SLAB,        // 1 = deterministic slab reduction instead of atomics (reserved)
+    OPT_BWW_SLAB,        // 1 (default) = per-split slabs + ordered sum (deterministic); 0 = fp32 atomics
+    OPT_BWW_MT,          // 0 = auto; 1/2/4 = row tiles (of 32) per wave in the dW kernel
     OPT_DBG,             // timing experiments only (results become wrong): bit0 = A operand from one cached line
     OPT_COUNT
 };

@@ -34,7 +34,7 @@ SIGNATURES = {
     "xdfm_cin_bwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "xdfm_cin_level_bwd_x": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
-    "xdfm_cin_bwd_w_ws_elems": (c_size_t, [c_int, c_int, c_int]),
+    "xdfm_cin_bwd_w_ws_elems": (c_size_t, [c_int, c_int, c_int, c_long]),
     "xdfm_cin_level_bwd_w": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),

@@ -283,7 +283,7 @@ class CINStack(torch.autograd.Function):
                                          fm if pool == "sum" else N, off, dir0, drows, _ptr(dOut), _ptr(dbias),
                                          _stream()), "cin_dout")
             if ctx.needs_input_grad[7 + 2 * l]:
-                ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m), dtype=torch.float32, device=dev)
+                ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m, N), dtype=torch.float32, device=dev)
                 dW = torch.empty((H, Hp * m), dtype=torch.float32, device=dev)
                 _lib.check(_run("cin_level_bwd_w", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_w(
                     _ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW), _stream())), "cin_level_bwd_w")
