@@ -409,7 +409,7 @@ def test_attention_kernel_vs_float64_oracle(variant, B, m, D, ls, heads, ln, res
 
     def scaled(got, ref, name):
         ref = ref.numpy()
-        close(got, ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-9, msg=name)
+        close(got, ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 5e-6, msg=name)   # 5e-6: fp32 noise floor where the exact gradient vanishes
     scaled(xg.grad, x64.grad, "dx")
     for k, p in layer.named_parameters():
         scaled(p.grad, st64["cin." + k].grad, k)

@@ -198,33 +198,49 @@ class BaseModel(nn.Module):
         weight_list = [weight_list] if isinstance(weight_list, nn.parameter.Parameter) else list(weight_list)
         self.regularization_weight.append((weight_list, l1, l2))
 
-    def get_regularization_loss(self, _defer_tables=False):
-        """sum over groups of l1*|w| + l2*w^2 (basemodel.py:412-428), shape [1].  All l2 groups are
-        evaluated by one multi-tensor launch (K6) instead of four ATen calls per tensor.
-
-        `_defer_tables` is used by the model's own train step only: the L2 gradient of the embedding
-        tables is then produced inside the gather's backward (as the initial value of the dense table
-        gradients) instead of as separate table-sized tensors that autograd has to add."""
-        l2_terms, total = [], None
+    def _l2_terms(self):
+        """[(tensor, l2 strength)] of every regularised tensor with l2 > 0, and the summed l1 term."""
+        l2_terms, l1_total = [], None
         for weight_list, l1, l2 in self.regularization_weight:
             for w in weight_list:
                 p = w[1] if isinstance(w, tuple) else w
                 if l1 > 0:
                     term = torch.sum(l1 * torch.abs(p))
-                    total = term if total is None else total + term
+                    l1_total = term if l1_total is None else l1_total + term
                 if l2 > 0:
                     l2_terms.append((p, float(l2)))
+        return l2_terms, l1_total
+
+    def _gather_tables(self):
+        """The tensors the fused gather reads, in its order (None before the first forward)."""
+        if self._plan is None or not getattr(self, "_fused_linear", False):
+            return None
+        return [self.embedding_dict[fc.embedding_name].weight for fc in self._sparse_cols] + \
+            self.linear_model.tables()
+
+    def get_regularization_loss(self, _defer_tables=False, _part="all"):
+        """sum over groups of l1*|w| + l2*w^2 (basemodel.py:412-428), shape [1].  All l2 groups are
+        evaluated by one multi-tensor launch (K6) instead of four ATen calls per tensor.
+
+        The private arguments are used by the model's own train step only.  `_defer_tables`: the L2
+        gradient of the embedding tables is produced inside the gather's backward (as the initial value
+        of the dense table gradients) instead of as table-sized tensors that autograd has to add.
+        `_part`: "all", or "tables" / "rest" to split the term (row-parallel training adds the rest
+        after the gradient all-reduce)."""
+        l2_terms, total = self._l2_terms()
+        tables = self._gather_tables()
+        table_ids = {id(t) for t in tables} if tables is not None else set()
+        if _part == "tables":
+            l2_terms, total = [x for x in l2_terms if id(x[0]) in table_ids], None
+        elif _part == "rest":
+            l2_terms = [x for x in l2_terms if id(x[0]) not in table_ids]
         if l2_terms:
             cache = self.__dict__.setdefault("_l2_cache", {})
             embed_plan, n_defer = None, 0
-            if _defer_tables and self._plan is not None and getattr(self, "_fused_linear", False) \
-                    and self._plan.dp is None:
-                tables = [self.embedding_dict[fc.embedding_name].weight for fc in self._sparse_cols] + \
-                    self.linear_model.tables()
+            if _defer_tables and tables is not None and _part != "rest":
                 coeff_of = {id(p): c for p, c in l2_terms}
                 if all(id(t) in coeff_of for t in tables) and all(t.requires_grad for t in tables):
-                    ids = {id(t) for t in tables}
-                    l2_terms = [(t, coeff_of[id(t)]) for t in tables] + [x for x in l2_terms if id(x[0]) not in ids]
+                    l2_terms = [(t, coeff_of[id(t)]) for t in tables] + [x for x in l2_terms if id(x[0]) not in table_ids]
                     embed_plan, n_defer = self._plan, len(tables)
             term = ops.l2_regulariser([p for p, _ in l2_terms], [c for _, c in l2_terms], cache, embed_plan, n_defer)
             total = term if total is None else total + term
@@ -250,13 +266,16 @@ class BaseModel(nn.Module):
             total_loss = loss + reg_loss + self.aux_loss
             total_loss.backward()
         else:
-            # data-loss gradients are SUMMED over ranks (the loss is a sum over the global batch); the
-            # L2 term is identical on every replica and is added once, locally, after the reduce.
-            reg_loss = self.get_regularization_loss()
-            loss.backward()
+            # Data-loss gradients are SUMMED over ranks (the loss is a sum over the global batch); the L2
+            # term is identical on every replica and must be applied once.  Tables: their gradient is
+            # built from the all-gathered rows (identical on all ranks) with the L2 term folded in.
+            # Dense weights: all-reduce the data gradients, then add the L2 gradient locally.
+            reg_t = self.get_regularization_loss(_defer_tables=True, _part="tables")
+            reg_d = self.get_regularization_loss(_part="rest")
+            (loss + reg_t).backward()
             dp.reduce_dense_grads(self)
-            (reg_loss + self.aux_loss).backward()
-            total_loss = loss.detach() + reg_loss.detach() + self.aux_loss
+            (reg_d + self.aux_loss).backward()
+            total_loss = loss.detach() + reg_t.detach() + reg_d.detach() + self.aux_loss
         self.optim.step()
         return y_pred, loss, total_loss
 
