@@ -123,3 +123,26 @@ def test_fm_layout_roundtrip():
     fm = ops.to_fm_layout(x)
     assert fm.shape == (3, 8) and float(fm[1, 4 + 2]) == float(x[1, 1, 2])
     assert torch.equal(ops.from_fm_layout(fm, 2, 4), x)
+
+
+def test_epoch_order_reproduces_dataloader_batches():
+    """fit's vectorised batching must visit the rows in the order DataLoader(shuffle=...) of the
+    reference's fit would (deepctr/models/basemodel.py:213-214,241) for the same torch seed, epoch after
+    epoch, and leave the default generator in the same state."""
+    import torch.utils.data as Data
+    from xdfm_amd.models import epoch_order
+    n, bs = 103, 16
+    X = torch.arange(n, dtype=torch.float64).view(n, 1)
+    for shuffle in (True, False):
+        torch.manual_seed(1024)
+        loader = Data.DataLoader(Data.TensorDataset(X, X), shuffle=shuffle, batch_size=bs)
+        want = [[b[0].view(-1).tolist() for b in loader] for _ in range(3)]
+        tail_ref = torch.rand(3)
+        torch.manual_seed(1024)
+        got = []
+        for _ in range(3):
+            order = epoch_order(n, shuffle)
+            rows = X if order is None else X.index_select(0, order)
+            got.append([rows[i:i + bs].view(-1).tolist() for i in range(0, n, bs)])
+        assert got == want
+        assert torch.equal(torch.rand(3), tail_ref)

@@ -16,8 +16,6 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-import torch.utils.data as Data
-from torch.utils.data import DataLoader
 
 from . import dist as xdist
 from . import metrics as M
@@ -38,6 +36,24 @@ def _slice(arrays, start=None, stop=None):
     if isinstance(arrays, (list, tuple)):
         return [None if a is None else a[start:stop] for a in arrays]
     return arrays[start:stop]
+
+
+def epoch_order(n, shuffle):
+    """Row order of one epoch, drawn exactly as `DataLoader(TensorDataset, shuffle=shuffle)` draws it
+    (basemodel.py:213-214, :241): creating the iterator takes one int64 from the default generator (its
+    base seed), then RandomSampler takes one more as the seed of a fresh generator for randperm.  The
+    same primitives in the same order give the same batches as the reference for a given torch seed --
+    without DataLoader's per-sample indexing and 4096-way collate (tens of ms per batch)."""
+    torch.empty((), dtype=torch.int64).random_()
+    if not shuffle:
+        return None
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    gen = torch.Generator()
+    gen.manual_seed(seed)
+    return torch.randperm(n, generator=gen)
+
+
+RESIDENT_LIMIT_BYTES = 64 << 30     # keep the packed fp32 input matrix on the device up to this size
 
 
 def _reject_varlen(cols):
@@ -346,6 +362,22 @@ class BaseModel(nn.Module):
         x = [np.expand_dims(a, axis=1) if len(a.shape) == 1 else a for a in x]
         return np.concatenate(x, axis=-1)
 
+    def _resident(self, x, y=None):
+        """The packed inputs as float32 tensors -- what `x.to(device).float()` (basemodel.py:242-243) yields
+        batch by batch -- placed on the model's device once when they fit, otherwise kept on the host."""
+        X = torch.from_numpy(np.ascontiguousarray(self._as_matrix(x))).float()
+        Y = None if y is None else torch.from_numpy(np.asarray(y)).float()
+        if X.numel() * 4 <= RESIDENT_LIMIT_BYTES:
+            X = X.to(self.device)
+            Y = None if Y is None else Y.to(self.device)
+        return X, Y
+
+    @staticmethod
+    def _rows(t, order, start, stop):
+        if order is None:
+            return t[start:stop]
+        return t.index_select(0, order[start:stop])
+
     # ------------------------------------------------------------------ fit / evaluate / predict
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, initial_epoch=0, validation_split=0.,
             validation_data=None, shuffle=True, callbacks=None):
@@ -374,7 +406,7 @@ class BaseModel(nn.Module):
             x, val_x = _slice(x, 0, split_at), _slice(x, split_at)
             y, val_y = _slice(y, 0, split_at), _slice(y, split_at)
 
-        data = Data.TensorDataset(torch.from_numpy(self._as_matrix(x)), torch.from_numpy(y))
+        X_all, Y_all = self._resident(x, y)
         if batch_size is None:
             batch_size = 256
         self.train()
@@ -384,8 +416,7 @@ class BaseModel(nn.Module):
         if dp is None:
             print(self.device)
         global_bs = batch_size * (dp.world if dp is not None else 1)   # `batch_size` is per GPU, as basemodel.py:209
-        loader = DataLoader(dataset=data, shuffle=shuffle, batch_size=global_bs)
-        sample_num = len(data)
+        sample_num = X_all.shape[0]
         steps_per_epoch = (sample_num - 1) // global_bs + 1
 
         cbs = CallbackList((callbacks or []) + [self.history])
@@ -394,20 +425,25 @@ class BaseModel(nn.Module):
         cbs.set_model(self)
         self.stop_training = False
         print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
-            len(data), len(val_y), steps_per_epoch))
+            sample_num, len(val_y), steps_per_epoch))
         for epoch in range(initial_epoch, epochs):
             cbs.on_epoch_begin(epoch)
             epoch_logs, train_result = {}, {}
-            start = time.time()
+            t_epoch = time.time()
             total_loss_epoch = 0.0
-            it = enumerate(loader)
+            order = epoch_order(sample_num, shuffle)
+            if order is not None:
+                order = order.to(X_all.device)
+            it = range(0, sample_num, global_bs)
             bar = tqdm(it, disable=verbose != 1) if tqdm is not None else None
             try:
-                for _, (xb, yb) in (bar if bar is not None else it):
+                for start in (bar if bar is not None else it):
+                    xb = self._rows(X_all, order, start, start + global_bs)
+                    yb = self._rows(Y_all, order, start, start + global_bs)
                     if dp is not None:
                         xb, yb = dp.shard(xb), dp.shard(yb)
-                    xd = xb.to(self.device).float()
-                    yd = yb.to(self.device).float()
+                    xd = xb.to(self.device)
+                    yd = yb.to(self.device)
                     y_pred, loss, total_loss = self.train_on_batch(xd, yd)
                     if dp is None:
                         total_loss_epoch += total_loss.item()
@@ -433,7 +469,7 @@ class BaseModel(nn.Module):
                 for name, val in self.evaluate(val_x, val_y, batch_size).items():
                     epoch_logs["val_" + name] = val
             if verbose > 0 and (dp is None or dp.rank == 0):
-                msg = "{0}s - loss: {1: .4f}".format(int(time.time() - start), epoch_logs["loss"])
+                msg = "{0}s - loss: {1: .4f}".format(int(time.time() - t_epoch), epoch_logs["loss"])
                 for name in self.metrics:
                     msg += " - " + name + ": {0: .4f}".format(epoch_logs[name])
                 if do_validation:
@@ -458,16 +494,15 @@ class BaseModel(nn.Module):
 
     def predict(self, x, batch_size=256):
         """float64 [N, 1] predictions (basemodel.py:325-352)."""
-        model = self.eval()
-        data = Data.TensorDataset(torch.from_numpy(self._as_matrix(x)))
-        loader = DataLoader(dataset=data, shuffle=False, batch_size=batch_size)
+        self.eval()
+        X_all, _ = self._resident(x)
         chunks = []
         with torch.no_grad():
-            for (xb,) in loader:
-                chunks.append(model(xb.to(self.device).float()))
+            for start in range(0, X_all.shape[0], batch_size):
+                chunks.append(self(X_all[start:start + batch_size].to(self.device)))
         if not chunks:
             return np.zeros((0, 1), dtype="float64")
-        return torch.cat(chunks).cpu().data.numpy().astype("float64")
+        return torch.cat(chunks).cpu().data.numpy().astype("float64")     # one device-to-host copy
 
 
 # ------------------------------------------------------------------------------------------------- #
