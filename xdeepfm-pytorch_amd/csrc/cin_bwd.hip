@@ -462,6 +462,178 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// v3 of the dW kernel (N % 4 == 0): same structure as the dword-DMA kernel, fewer instructions per
+// MFMA (with two waves per SIMD the shared vector-issue port, not the matrix pipe, was the limiter):
+//   * operands arrive by 16-byte LDS-DMA (global_load_lds_dwordx4: 8 rows x 32 columns per
+//     instruction, 9 instructions per wave and chunk instead of 33);
+//   * LDS image: row r, 16-byte chunk q (4 columns) at r*32 + (q ^ (r & 7))*4 floats;
+//   * the contraction index is re-ordered so that one ds_read_b64 feeds two k-steps: k-step t,
+//     lane half s  <->  column 4*(t>>1) + 2*s + (t&1)  (A and B operands use the same map).
+__device__ __forceinline__ void dma_x4(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int MT, int JT>
+__global__ __launch_bounds__(256, 2) void cin_bwd_w_dma4_kernel(
+    const float* __restrict__ dOut, const float* __restrict__ xp, const float* __restrict__ x0,
+    int H, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad, int IPAD,
+    float* __restrict__ dWt, long slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(JT == 2, "x0 rows are staged as one (half-masked) DMA instruction");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, s = lane >> 5;
+    const int wt0 = blockIdx.x * 4;
+    const int hg = wt0 / TPH;
+    const int tin = wt0 + wave - hg * TPH;
+    const bool active = tin < JP * IB;
+    const int jp = active ? tin / IB : 0;
+    const int iblk = active ? tin - jp * IB : 0;
+    const long n_begin = (long)blockIdx.y * n_per_split;
+    const long n_end = (n_begin + n_per_split < N) ? n_begin + n_per_split : N;
+    const int nfull = (int)((n_end - n_begin) / BWW_NC);
+
+    constexpr int DROWS = 32 * MT;
+    constexpr int WROWS = 32 + 8;                       // x_prev block + one 8-row group holding the x0 rows
+    constexpr int BUF = (DROWS + 4 * WROWS) * 32;
+    constexpr int ND_D = DROWS / 32;                    // dOut DMA instructions per wave (8 rows each)
+    constexpr int NDMA = ND_D + 4 + 1;
+
+    // lane -> (row within the 8-row group, physical chunk); logical chunk = pc ^ (row & 7)
+    const int lrow = lane >> 3, pc = lane & 7;
+    const int lcol = (pc ^ lrow) * 4;                   // (row & 7) == lrow because groups start at multiples of 8
+    const int drow0 = wave * (DROWS / 4);
+
+    auto dma_k = [&](int k, long nc0, int buf) {
+        float* base = smem + buf * BUF;
+        if (k < ND_D) {
+            const int row = drow0 + 8 * k + lrow;
+            int h = hg * DROWS + row;
+            h = h < H ? h : H - 1;
+            dma_x4(dOut + (long)h * N + nc0 + lcol, base + (drow0 + 8 * k) * 32);
+        } else if (k < ND_D + 4) {
+            const int kk = k - ND_D;
+            float* wb = base + DROWS * 32 + wave * (WROWS * 32);
+            int i = iblk * 32 + 8 * kk + lrow;
+            i = i < Hp ? i : Hp - 1;
+            dma_x4(xp + (long)i * N + nc0 + lcol, wb + (8 * kk) * 32);
+        } else {
+            float* wb = base + DROWS * 32 + wave * (WROWS * 32) + 32 * 32;
+            int j = jp * JT + (lrow < JT ? lrow : JT - 1);     // rows >= JT of the group are never read
+            j = j < m ? j : m - 1;
+            dma_x4(x0 + (long)j * N + nc0 + lcol, wb);
+        }
+    };
+
+    f32x16 acc[MT][JT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][jt][r] = 0.f;
+
+    constexpr int USTEPS = BWW_NC / 4;                  // pairs of k-steps per chunk
+    auto compute = [&](int buf, long next_nc0, int next_buf) {
+        const float* dS = smem + buf * BUF;
+        const float* xS = dS + DROWS * 32 + wave * (WROWS * 32);
+        const float* zS = xS + 32 * 32;
+        const bool has_next = next_nc0 >= 0;
+#pragma unroll
+        for (int u = 0; u < USTEPS; ++u) {
+            // 8-byte pair s of logical chunk u of row r sits at r*32 + (u ^ (r&7))*4 + 2*s
+            float2 a[MT], b2[JT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const float2*>(dS + (mt * 32 + c) * 32 + ((u ^ (c & 7)) * 4 + 2 * s));
+            const float2 xv = *reinterpret_cast<const float2*>(xS + c * 32 + ((u ^ (c & 7)) * 4 + 2 * s));
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const float2 z = *reinterpret_cast<const float2*>(zS + jt * 32 + ((u ^ jt) * 4 + 2 * s));
+                b2[jt] = make_float2(xv.x * z.x, xv.y * z.y);
+            }
+            if (has_next) {
+                if (u < NDMA) dma_k(u, next_nc0, next_buf);
+                if (u == USTEPS - 1) {
+#pragma unroll
+                    for (int k = USTEPS; k < NDMA; ++k) dma_k(k, next_nc0, next_buf);
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].x, b2[jt].x, acc[mt][jt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt].y, b2[jt].y, acc[mt][jt], 0, 0, 0);
+        }
+    };
+
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) dma_k(k, n_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int ch = 0; ch < nfull; ++ch) {
+        const long nxt = (ch + 1 < nfull) ? n_begin + (long)(ch + 1) * BWW_NC : -1;
+        compute(ch & 1, nxt, (ch + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // tail chunk (fewer than 32 valid columns): masked register staging into buffer 0, same image
+    const long nt0 = n_begin + (long)nfull * BWW_NC;
+    if (nt0 < n_end) {
+        float* base = smem;
+        const long n = nt0 + c;
+        const float cm = (n < n_end) ? 1.f : 0.f;
+        const long ncl = n < N ? n : N - 1;
+        auto img = [&](int row, int col) { return row * 32 + (((col >> 2) ^ (row & 7)) * 4 + (col & 3)); };
+#pragma unroll
+        for (int k = 0; k < DROWS / 8; ++k) {
+            const int row = drow0 + 2 * k + s;
+            const int h = hg * DROWS + row;
+            base[img(row, c)] = dOut[(long)(h < H ? h : H - 1) * N + ncl] * ((h < H) ? cm : 0.f);
+        }
+        float* wb = base + DROWS * 32 + wave * (WROWS * 32);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = 2 * k + s;
+            const int i = iblk * 32 + row;
+            wb[img(row, c)] = xp[(long)(i < Hp ? i : Hp - 1) * N + ncl] * ((i < Hp) ? cm : 0.f);
+        }
+        {
+            const int j = jp * JT + s;
+            wb[32 * 32 + img(s, c)] = x0[(long)(j < m ? j : m - 1) * N + ncl] * ((j < m) ? cm : 0.f);
+        }
+        __syncthreads();
+        compute(0, -1, 0);
+    }
+
+    if (!active) return;
+    const int i = iblk * 32 + c;
+    float* __restrict__ dst = dWt + (long)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j = jp * JT + jt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = hg * 32 * MT + mt * 32 + frag_row(r, s);
+                if (h < H && i < Hp && j < m) {
+                    if (slab_stride) dst[((long)j * Hpad + h) * IPAD + i] = acc[mt][jt][r];
+                    else atomicAdd(&dst[((long)j * Hpad + h) * IPAD + i], acc[mt][jt][r]);
+                }
+            }
+        }
+}
+
 // dW[h][i*m+j] = sum over n-splits of dWt[split][j][h][i]; threads walk the dWt layout (i fastest) so
 // the slab reads are coalesced.
 __global__ void cin_bwd_w_unpack_kernel(const float* __restrict__ dWt, int H, int Hp, int m, int Hpad, int IPAD,
@@ -543,6 +715,11 @@ static int launch_bwd_w(const float* dOut, const float* xp, const float* x0, int
         const size_t lds = (size_t)(32 * MT + 4 * (32 + JT)) * BWW_PITCH * sizeof(float);
         hipLaunchKernelGGL((cin_bwd_w_kernel<MT, JT>), dim3(g.gx, g.nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp, m,
                            N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, ws);
+    } else if (MT == 4 && N % 4 == 0 && !(xdfm_opt(OPT_DBG) & 16) &&
+               ((((size_t)dOut) | ((size_t)xp) | ((size_t)x0)) & 15) == 0) {
+        const size_t lds = (size_t)2 * (32 * MT + 4 * (32 + 8)) * 32 * sizeof(float);
+        hipLaunchKernelGGL((cin_bwd_w_dma4_kernel<MT, JT>), dim3(g.gx, g.nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp,
+                           m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, ws, stride);
     } else {
         const size_t lds = (size_t)2 * (32 * MT + 4 * (32 + JT)) * 32 * sizeof(float);
         hipLaunchKernelGGL((cin_bwd_w_dma_kernel<MT, JT>), dim3(g.gx, g.nsplit), dim3(256), lds, st, dOut, xp, x0, H, Hp,
