@@ -142,16 +142,18 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
  *        ([D] each, only if use_ln); then W1 [D][D], b1 [D], w2 [D]  (xdfm_cin_attn_theta_elems floats).
  * nh     number of heads (must divide D; pairs (D, nh) are compiled for D in {4,8,10,16,32}).
  * out    [B][D] pooled vector.  (CINAttention's output_proj D -> featuremap_num is a plain GEMM.)
- * tok_save [n_layers][B][S][D], ml_save [n_layers][B][S][nh][2]: written by fwd, read by bwd.
+ * tok_save, o_save [n_layers][B][S][D] (each layer's output tokens / attention output before W_o),
+ * ml_save [n_layers][B][S][nh][2] (softmax max, 1/sum): written by fwd, read by bwd.
  * bwd: dout [B][D]; dfm [S][B*D] is overwritten; dtheta (same layout as theta) is ACCUMULATED into with
  * fp32 atomics and must be zeroed by the caller.  S <= 1024.
  */
 size_t xdfm_cin_attn_theta_elems(int D, int n_layers, int use_ln);
 int xdfm_cin_attn_pool_fwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
-                           const float* theta, float* out, float* tok_save, float* ml_save, void* stream);
+                           const float* theta, float* out, float* tok_save, float* o_save, float* ml_save,
+                           void* stream);
 int xdfm_cin_attn_pool_bwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
-                           const float* theta, const float* tok_save, const float* ml_save, const float* dout,
-                           float* dfm, float* dtheta, void* stream);
+                           const float* theta, const float* tok_save, const float* o_save, const float* ml_save,
+                           const float* dout, float* dfm, float* dtheta, void* stream);
 
 /* ------------------------------------------------------------------ L2 regulariser (K6)
  * replaces: deepctr/models/basemodel.py:412-428 (per-tensor square / mul / sum / add loop over

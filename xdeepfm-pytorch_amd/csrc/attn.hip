@@ -134,9 +134,9 @@ __device__ __forceinline__ void head_scores(const float (&q)[D], const float (&k
 // (post residual / LayerNorm), which is also returned in a.  Ks/Vs: [S][D] LDS; WT: this layer's
 // weights in LDS, matrices transposed.  mx / ls: softmax statistics of the thread's query row.
 template <int D, int NH>
-__device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&mx)[NH], float (&ls)[NH], float* Xs, float* Ks,
-                                               float* Vs, const float* WT, int S, bool live, int use_ln,
-                                               int use_res) {
+__device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], float (&mx)[NH], float (&ls)[NH],
+                                               float* Xs, float* Ks, float* Vs, const float* WT, int S, bool live,
+                                               int use_ln, int use_res) {
     constexpr int HD = D / NH;
     constexpr int XP = D + 1;
     const int s = threadIdx.x;
@@ -190,7 +190,10 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&mx)[NH], f
     for (int h = 0; h < NH; ++h) {
         const float inv = 1.0f / ls[h];
 #pragma unroll
-        for (int e = 0; e < HD; ++e) xrow[h * HD + e] = o[h * HD + e] * inv;     // own row: no barrier needed
+        for (int e = 0; e < HD; ++e) {
+            on[h * HD + e] = o[h * HD + e] * inv;
+            xrow[h * HD + e] = on[h * HD + e];                              // own row: no barrier needed
+        }
     }
     matvec_acc<D>(WT + 3 * D * D, xrow, a);
     if (use_ln) {
@@ -216,7 +219,7 @@ template <int D, int NH, int TB>
 __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
     const float* __restrict__ fm, long N, int B, int S, int n_layers, int use_ln, int use_res,
     const float* __restrict__ theta, float* __restrict__ out, float* __restrict__ tok_save,
-    float* __restrict__ ml_save) {
+    float* __restrict__ o_save, float* __restrict__ ml_save) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int XP = D + 1;
     float* Ks = smem;                                    // [S][D]
@@ -237,11 +240,13 @@ __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
         __syncthreads();                                 // previous layer's reads of Ks/Vs/Ws are done
         stage_weights_t<D>(Ws, theta + (long)layer * lsz, 4, use_ln ? 2 * D : 0);
         __syncthreads();
-        float a[D], mx[NH], ls[NH];
-        mhsa_layer_fwd<D, NH>(a, mx, ls, Xs, Ks, Vs, Ws, S, live, use_ln, use_res);
+        float a[D], on[D], mx[NH], ls[NH];
+        mhsa_layer_fwd<D, NH>(a, on, mx, ls, Xs, Ks, Vs, Ws, S, live, use_ln, use_res);
         if (live) {
-            // saved for backward: the layer's output tokens and its softmax statistics (max, 1/sum)
+            // saved for backward: the layer's output tokens, its attention output (before W_o) and the
+            // softmax statistics (max, 1/sum) of every query row
             store_row<D>(tok_save + (((long)layer * B + b) * S + s) * D, a);
+            store_row<D>(o_save + (((long)layer * B + b) * S + s) * D, on);
             float* ml = ml_save + ((((long)layer * B + b) * S + s) * NH) * 2;
 #pragma unroll
             for (int h = 0; h < NH; ++h) { ml[2 * h] = mx[h]; ml[2 * h + 1] = 1.0f / ls[h]; }
@@ -296,15 +301,16 @@ static size_t attn_fwd_lds(int S, int D) {
 
 template <int D, int NH>
 static int launch_attn_fwd(const float* fm, int B, int S, int n_layers, int use_ln, int use_res,
-                           const float* theta, float* out, float* tok_save, float* ml_save, hipStream_t st) {
+                           const float* theta, float* out, float* tok_save, float* o_save, float* ml_save,
+                           hipStream_t st) {
     const int threads = (int)round_up(S, 64);
     const size_t lds = attn_fwd_lds(S, D);
     if (threads <= 512)
         hipLaunchKernelGGL((attn_pool_fwd_kernel<D, NH, 512>), dim3(B), dim3(threads), lds, st, fm, (long)B * D, B, S,
-                           n_layers, use_ln, use_res, theta, out, tok_save, ml_save);
+                           n_layers, use_ln, use_res, theta, out, tok_save, o_save, ml_save);
     else
         hipLaunchKernelGGL((attn_pool_fwd_kernel<D, NH, 1024>), dim3(B), dim3(threads), lds, st, fm, (long)B * D, B, S,
-                           n_layers, use_ln, use_res, theta, out, tok_save, ml_save);
+                           n_layers, use_ln, use_res, theta, out, tok_save, o_save, ml_save);
     return xdfm_check_launch("cin_attn_pool_fwd");
 }
 
@@ -332,14 +338,16 @@ static int launch_attn_fwd(const float* fm, int B, int S, int n_layers, int use_
 // =============================================================================================
 // backward
 // =============================================================================================
-// dst[i*D + d] += sum_s A[s][i] * Bm[s][d]   (A, Bm: [S][pitch] LDS tiles; dst: LDS accumulator)
+// dst[i*D + d] += sum_s A[s][i] * G[s*gp + d]   (A: [S][pitch] LDS tile; G: rows in global memory,
+// pitch gp -- the layer's input tokens or its saved attention output, L2-resident)
 template <int D>
-__device__ __forceinline__ void outer_accumulate(float* __restrict__ dst, const float* __restrict__ A,
-                                                 const float* __restrict__ Bm, int pitch, int S) {
+__device__ __forceinline__ void outer_accumulate(float* __restrict__ dst, const float* __restrict__ A, int pitch,
+                                                 const float* __restrict__ G, long gp, int S) {
     for (int idx = threadIdx.x; idx < D * D; idx += blockDim.x) {
         const int i = idx / D, d = idx - i * D;
         float acc = 0.f;
-        for (int s = 0; s < S; ++s) acc = fmaf(A[s * pitch + i], Bm[s * pitch + d], acc);
+#pragma unroll 4
+        for (int s = 0; s < S; ++s) acc = fmaf(A[s * pitch + i], G[(long)s * gp + d], acc);
         dst[idx] += acc;
     }
 }
@@ -356,15 +364,13 @@ __device__ __forceinline__ void vec_accumulate(float* __restrict__ dst, const fl
 
 // LDS carve-up of the backward kernel (floats).  TP = rows of the per-thread tiles = blockDim.
 struct AttnBwdLds {
-    int kv, x, y, z, st, w, acc, red, total;
+    int kv, z, st, w, acc, red, total;
 };
 static __host__ __device__ inline AttnBwdLds attn_bwd_layout(int S, int D, int NH, int n_layers, int TP) {
     AttnBwdLds L;
     int off = 0;
     L.kv = off;  off += 2 * S * D;                   // K,V  then Q,dO
-    L.x = off;   off += TP * (D + 1);                // tokens entering the stage (one row per thread)
-    L.y = off;   off += TP * (D + 1);                // scratch tile (o / do / dq ...)
-    L.z = off;   off += TP * (D + 1);                // scratch tile (dy / du / dk ...)
+    L.z = off;   off += TP * (D + 1);                // the one per-thread tile: dy / du / dq / dk / dv rows
     L.st = off;  off += S * 3 * NH;                  // per query: max, 1/sum, delta  per head
     L.w = off;   off += 8 * D * D + 2 * D;           // transposed + plain weights of the stage
     L.acc = off; off += n_layers * (4 * D * D + 2 * D) + D * D + 2 * D;   // parameter-gradient accumulator
@@ -376,16 +382,15 @@ static __host__ __device__ inline AttnBwdLds attn_bwd_layout(int S, int D, int N
 template <int D, int NH, int TB>
 __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
     const float* __restrict__ fm, long N, int B, int S, int n_layers, int use_ln, int use_res,
-    const float* __restrict__ theta, const float* __restrict__ tok_save, const float* __restrict__ ml_save,
-    const float* __restrict__ dout, float* __restrict__ dfm, float* __restrict__ dtheta) {
+    const float* __restrict__ theta, const float* __restrict__ tok_save, const float* __restrict__ o_save,
+    const float* __restrict__ ml_save, const float* __restrict__ dout, float* __restrict__ dfm,
+    float* __restrict__ dtheta) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = D / NH;
     constexpr int XP = D + 1;
     const AttnBwdLds L = attn_bwd_layout(S, D, NH, n_layers, blockDim.x);
     float* Ks = smem + L.kv;
     float* Vs = Ks + S * D;
-    float* Xs = smem + L.x;
-    float* Ys = smem + L.y;
     float* Zs = smem + L.z;
     float* St = smem + L.st;
     float* WT = smem + L.w;                 // 4 transposed matrices (forward products)
@@ -397,9 +402,8 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
     const int lsz = 4 * D * D + (use_ln ? 2 * D : 0);
     const int asz = n_layers * lsz + D * D + 2 * D;
     const float scale = 1.0f / sqrtf((float)HD);
-    float* xrow = Xs + s * XP;
-    float* yrow = Ys + s * XP;
     float* zrow = Zs + s * XP;
+    const int sl = live ? s : 0;                // dead threads read row 0 and contribute nothing
 
     for (int i = threadIdx.x; i < asz; i += blockDim.x) Acc[i] = 0.f;
 
@@ -410,13 +414,8 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
         __syncthreads();
         stage_weights_t<D>(WT, tp, 1, 0);                                   // W1^T
         for (int i = threadIdx.x; i < D * D + 2 * D; i += blockDim.x) WN[i] = tp[i];   // W1, b1, w2
-        {
-            const float* src = tok_save + (((long)(n_layers - 1) * B + b) * S + s) * D;
-            float x[D];
-            if (live) load_row<D>(src, x);
-#pragma unroll
-            for (int d = 0; d < D; ++d) xrow[d] = live ? x[d] : 0.f;
-        }
+        const float* tok_in = tok_save + ((long)(n_layers - 1) * B + b) * S * D;   // tokens entering the pooling
+        const float* xrow = tok_in + (long)sl * D;       // this thread's token (global, L1/L2 resident)
         __syncthreads();
         float da[D];                                     // gradient w.r.t. the tokens entering the pooling
         {
@@ -437,6 +436,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             float dalpha = 0.f;
 #pragma unroll
             for (int d = 0; d < D; ++d) dalpha = fmaf(xrow[d], dpool[d], dalpha);
+            if (!live) dalpha = 0.f;
             const float c = block_sum(alpha * dalpha, red);
             const float de = alpha * (dalpha - c);       // softmax backward
             float du[D], g2[D];
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             for (int d = 0; d < D; ++d) da[d] = alpha * dpool[d];
             matvec_acc<D>(WN, zrow, da);                 // += W1^T du
             __syncthreads();
-            outer_accumulate<D>(accp, Zs, Xs, XP, S);    // dW1[i][d] += sum_s du_s[i] x_s[d]
+            outer_accumulate<D>(accp, Zs, XP, tok_in, D, S);    // dW1[i][d] += sum_s du_s[i] x_s[d]
         }
 
         // ------------------------------------------------------------------ MHSA layers, last to first
@@ -462,19 +462,12 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             __syncthreads();                             // previous stage done with Xs / Zs / weights
             stage_weights_t<D>(WT, th_l, 4, 0);
             for (int i = threadIdx.x; i < lsz; i += blockDim.x) WN[i] = th_l[i];
-            {
-                float x[D];
-                if (live) {
-                    if (layer == 0) {
-#pragma unroll
-                        for (int d = 0; d < D; ++d) x[d] = fm[(long)s * N + (long)b * D + d];
-                    } else {
-                        load_row<D>(tok_save + (((long)(layer - 1) * B + b) * S + s) * D, x);
-                    }
-                }
-#pragma unroll
-                for (int d = 0; d < D; ++d) xrow[d] = live ? x[d] : 0.f;
-            }
+            // tokens entering this layer and its saved attention output: global rows (pitch xgp / D)
+            const float* xg = (layer == 0) ? fm + (long)b * D : tok_save + ((long)(layer - 1) * B + b) * S * D;
+            const long xgp = (layer == 0) ? N : D;
+            const float* og = o_save + ((long)layer * B + b) * S * D;
+            const float* xrow = xg + (long)sl * xgp;
+            const float* orow = og + (long)sl * D;
             float mx[NH], il[NH];
             {
                 const float* ml = ml_save + ((((long)layer * B + b) * S + (live ? s : 0)) * NH) * 2;
@@ -496,27 +489,14 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             __syncthreads();
             float o[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) o[d] = 0.f;
-#pragma unroll 2
-            for (int t = 0; t < S; ++t) {
-                float k[D], v[D], sc[NH];
-                load_row<D>(Ks + t * D, k);
-                load_row<D>(Vs + t * D, v);
-                head_scores<D, NH>(q, k, scale, sc);
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const float p = __expf(sc[h] - mx[h]) * il[h];
-#pragma unroll
-                    for (int e = 0; e < HD; ++e) o[h * HD + e] = fmaf(p, v[h * HD + e], o[h * HD + e]);
-                }
-            }
+            for (int d = 0; d < D; ++d) o[d] = live ? orow[d] : 0.f;
             // y = W_o o (+x), LayerNorm backward -> dy
             float dy[D];
             {
                 float y[D];
 #pragma unroll
-                for (int d = 0; d < D; ++d) { y[d] = use_res ? xrow[d] : 0.f; yrow[d] = o[d]; }
-                matvec_acc<D>(WT + 3 * D * D, yrow, y);
+                for (int d = 0; d < D; ++d) y[d] = use_res ? xrow[d] : 0.f;
+                matvec_acc<D>(WT + 3 * D * D, orow, y);
                 if (use_ln) {
                     const float* g = WN + 4 * D * D;
                     float mean = 0.f;
@@ -550,7 +530,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
 #pragma unroll
             for (int d = 0; d < D; ++d) zrow[d] = dy[d];
             __syncthreads();
-            outer_accumulate<D>(accl + 3 * D * D, Zs, Ys, XP, S);     // dWo[i][d] += sum_s dy_s[i] o_s[d]
+            outer_accumulate<D>(accl + 3 * D * D, Zs, XP, og, D, S);  // dWo[i][d] += sum_s dy_s[i] o_s[d]
             // do = W_o^T dy ; delta_h = do_h . o_h ; dx starts as the residual branch
             float dO[D], delta[NH], dx[D];
 #pragma unroll
@@ -601,7 +581,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
 #pragma unroll
             for (int d = 0; d < D; ++d) zrow[d] = dq[d];
             __syncthreads();
-            outer_accumulate<D>(accl, Zs, Xs, XP, S);    // dWq[i][d] += sum_s dq_s[i] x_s[d]
+            outer_accumulate<D>(accl, Zs, XP, xg, xgp, S);    // dWq[i][d] += sum_s dq_s[i] x_s[d]
             matvec_acc<D>(WN, zrow, dx);                 // dx += Wq^T dq
             // pass B (thread = key): dk, dv
             float dk[D], dv[D];
@@ -635,13 +615,13 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
 #pragma unroll
             for (int d = 0; d < D; ++d) zrow[d] = dk[d];
             __syncthreads();
-            outer_accumulate<D>(accl + D * D, Zs, Xs, XP, S);          // dWk
+            outer_accumulate<D>(accl + D * D, Zs, XP, xg, xgp, S);     // dWk
             matvec_acc<D>(WN + D * D, zrow, dx);                       // dx += Wk^T dk
             __syncthreads();
 #pragma unroll
             for (int d = 0; d < D; ++d) zrow[d] = dv[d];
             __syncthreads();
-            outer_accumulate<D>(accl + 2 * D * D, Zs, Xs, XP, S);      // dWv
+            outer_accumulate<D>(accl + 2 * D * D, Zs, XP, xg, xgp, S); // dWv
             matvec_acc<D>(WN + 2 * D * D, zrow, dx);                   // dx += Wv^T dv
             // dx is the gradient w.r.t. the tokens entering this layer
             if (layer == 0) {
@@ -661,18 +641,18 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
 
 template <int D, int NH>
 static int launch_attn_bwd(const float* fm, int B, int S, int n_layers, int use_ln, int use_res, const float* theta,
-                           const float* tok_save, const float* ml_save, const float* dout, float* dfm, float* dtheta,
-                           hipStream_t st) {
+                           const float* tok_save, const float* o_save, const float* ml_save, const float* dout,
+                           float* dfm, float* dtheta, hipStream_t st) {
     const int threads = (int)round_up(S, 64);
     const size_t lds = (size_t)attn_bwd_layout(S, D, NH, n_layers, threads).total * sizeof(float);
     if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_attn_pool_bwd: S=%d D=%d does not fit LDS", S, D);
-    const int grid = B < 1024 ? B : 1024;
+    const int grid = B < 2048 ? B : 2048;
     if (threads <= 512)
         hipLaunchKernelGGL((attn_pool_bwd_kernel<D, NH, 512>), dim3(grid), dim3(threads), lds, st, fm, (long)B * D, B, S,
-                           n_layers, use_ln, use_res, theta, tok_save, ml_save, dout, dfm, dtheta);
+                           n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta);
     else
         hipLaunchKernelGGL((attn_pool_bwd_kernel<D, NH, 1024>), dim3(grid), dim3(threads), lds, st, fm, (long)B * D, B, S,
-                           n_layers, use_ln, use_res, theta, tok_save, ml_save, dout, dfm, dtheta);
+                           n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta);
     return xdfm_check_launch("cin_attn_pool_bwd");
 }
 
@@ -683,23 +663,26 @@ size_t xdfm_cin_attn_theta_elems(int D, int n_layers, int use_ln) {
 }
 
 int xdfm_cin_attn_pool_fwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
-                           const float* theta, float* out, float* tok_save, float* ml_save, void* stream) {
-    XDFM_REQUIRE(fm && theta && out && ml_save && tok_save, "cin_attn_pool_fwd: null pointer");
+                           const float* theta, float* out, float* tok_save, float* o_save, float* ml_save,
+                           void* stream) {
+    XDFM_REQUIRE(fm && theta && out && ml_save && tok_save && o_save, "cin_attn_pool_fwd: null pointer");
     XDFM_REQUIRE(B > 0 && S > 0 && S <= 1024 && n_layers >= 1, "cin_attn_pool_fwd: bad shape B=%d S=%d layers=%d", B, S,
                  n_layers);
     XDFM_REQUIRE(attn_fwd_lds(S, D) <= 160 * 1024, "cin_attn_pool_fwd: S=%d D=%d does not fit LDS", S, D);
     hipStream_t st = (hipStream_t)stream;
-    ATTN_DISPATCH(launch_attn_fwd, fm, B, S, n_layers, use_ln, use_res, theta, out, tok_save, ml_save, st)
+    ATTN_DISPATCH(launch_attn_fwd, fm, B, S, n_layers, use_ln, use_res, theta, out, tok_save, o_save, ml_save, st)
 }
 
 int xdfm_cin_attn_pool_bwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
-                           const float* theta, const float* tok_save, const float* ml_save, const float* dout,
-                           float* dfm, float* dtheta, void* stream) {
-    XDFM_REQUIRE(fm && theta && tok_save && ml_save && dout && dfm && dtheta, "cin_attn_pool_bwd: null pointer");
+                           const float* theta, const float* tok_save, const float* o_save, const float* ml_save,
+                           const float* dout, float* dfm, float* dtheta, void* stream) {
+    XDFM_REQUIRE(fm && theta && tok_save && o_save && ml_save && dout && dfm && dtheta,
+                 "cin_attn_pool_bwd: null pointer");
     XDFM_REQUIRE(B > 0 && S > 0 && S <= 1024 && n_layers >= 1, "cin_attn_pool_bwd: bad shape B=%d S=%d layers=%d", B, S,
                  n_layers);
     hipStream_t st = (hipStream_t)stream;
-    ATTN_DISPATCH(launch_attn_bwd, fm, B, S, n_layers, use_ln, use_res, theta, tok_save, ml_save, dout, dfm, dtheta, st)
+    ATTN_DISPATCH(launch_attn_bwd, fm, B, S, n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta,
+                  st)
 }
 
 }  // extern "C"

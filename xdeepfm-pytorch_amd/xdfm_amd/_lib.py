@@ -37,8 +37,8 @@ SIGNATURES = {
     "xdfm_cin_bwd_w_ws_elems": (c_size_t, [c_int, c_int, c_int, c_long]),
     "xdfm_cin_level_bwd_w": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
-    "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
-    "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
     "xdfm_l2_reg_fwd": (c_int, [P, P, P, c_int, P, P, P]),
     "xdfm_l2_reg_bwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
 }

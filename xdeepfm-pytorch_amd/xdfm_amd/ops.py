@@ -347,20 +347,21 @@ class AttnPool(torch.autograd.Function):
         dev = fm.device
         out = torch.empty((B, D), dtype=torch.float32, device=dev)
         tok = torch.empty((n_layers, B, S, D), dtype=torch.float32, device=dev)
+        osv = torch.empty((n_layers, B, S, D), dtype=torch.float32, device=dev)
         ml = torch.empty((n_layers, B, S, nh, 2), dtype=torch.float32, device=dev)
         # S^2 * (3 D FMA) per example and layer, counted as 2 FLOP per FMA
         flops = 2.0 * 3 * D * S * S * B * n_layers
         _lib.check(_run("cin_attn_pool_fwd", flops, lambda: lib.xdfm_cin_attn_pool_fwd(
-            _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(out), _ptr(tok), _ptr(ml),
-            _stream())), "cin_attn_pool_fwd")
+            _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(out), _ptr(tok), _ptr(osv),
+            _ptr(ml), _stream())), "cin_attn_pool_fwd")
         ctx.cfg = (B, D, nh, n_layers, use_ln, use_res, [tuple(p.shape) for p in params])
-        ctx.save_for_backward(fm, theta, tok, ml)
+        ctx.save_for_backward(fm, theta, tok, osv, ml)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = _lib.load()
-        fm, theta, tok, ml = ctx.saved_tensors
+        fm, theta, tok, osv, ml = ctx.saved_tensors
         B, D, nh, n_layers, use_ln, use_res, shapes = ctx.cfg
         S = fm.shape[0]
         dfm = torch.empty_like(fm)
@@ -368,8 +369,8 @@ class AttnPool(torch.autograd.Function):
         dout = dout.contiguous()
         flops = 2.0 * 7 * D * S * S * B * n_layers
         _lib.check(_run("cin_attn_pool_bwd", flops, lambda: lib.xdfm_cin_attn_pool_bwd(
-            _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(tok), _ptr(ml), _ptr(dout),
-            _ptr(dfm), _ptr(dtheta), _stream())), "cin_attn_pool_bwd")
+            _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(tok), _ptr(osv), _ptr(ml),
+            _ptr(dout), _ptr(dfm), _ptr(dtheta), _stream())), "cin_attn_pool_bwd")
         grads, off = [], 0
         for sh in shapes:
             n = 1
