@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--option", action="append", default=[], help="libxdfm tuning knob key=value")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
+                    "to rehearse the multi-rank path with several ranks on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,8 +157,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        n_dev = torch.cuda.device_count()
+        local_rank = local_rank % max(n_dev, 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     if args.gpus != world:
         if rank == 0:
             print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
@@ -204,7 +211,7 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if not np.isfinite(float(loss.item())):
