@@ -438,3 +438,33 @@ def test_attention_kernel_vs_float64_oracle(variant, B, m, D, ls, heads, ln, res
     scaled(xg.grad, x64.grad, "dx")
     for k, p in layer.named_parameters():
         scaled(p.grad, st64["cin." + k].grad, k)
+
+
+def test_full_size_logloss_auc_vs_cpu_path():
+    """North-star check at BASELINE config-2 size: one 4096-row synthetic Criteo batch, identical weights,
+    predictions of the HIP path vs the CPU oracle -> logloss and AUC must agree within 1e-5."""
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from oracle import xdeepfm_oracle as orc
+    from xdfm_amd import metrics as M
+    dev = _dev()
+    vocab, nd, D, B = [3000] * 26, 13, 16, 4096
+    names = ["C%d" % (i + 1) for i in range(26)]
+    dnames = ["I%d" % (i + 1) for i in range(nd)]
+    cols = [SparseFeat(n, v, D) for n, v in zip(names, vocab)] + [DenseFeat(n, 1) for n in dnames]
+    model = xDeepFM(cols, cols, cin_layer_size=(256, 128, 128), dnn_hidden_units=(256, 256), device=dev)
+    g = torch.Generator().manual_seed(9)
+    with torch.no_grad():                      # lively weights so that the predictions spread over (0, 1)
+        for k, p in model.named_parameters():
+            if "embedding_dict" in k or "dnn" in k or k in ("linear_model.weight", "cin_linear.weight"):
+                p.copy_((0.2 * torch.randn(p.shape, generator=g)).to(dev))
+    X, y = orc.synthetic_batch(B, vocab, nd, seed=2025)
+    pred = model.predict({n: X[:, i] for i, n in enumerate(names + dnames)}, batch_size=B)
+    spec = orc.Spec(names, vocab, dnames, D, (256, 128, 128), True, "relu", (256, 256))
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        want = orc.model_forward(T(X), state, spec).numpy().astype("float64")
+    assert 0.02 < want.std()                                        # a non-degenerate batch
+    assert abs(M.log_loss(y, pred) - M.log_loss(y, want)) < 1e-5
+    assert abs(M.roc_auc_score(y, pred) - M.roc_auc_score(y, want)) < 1e-5
+    np.testing.assert_allclose(pred, want, rtol=1e-4, atol=2e-6)
