@@ -205,9 +205,11 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         loss = train_step(model, *batches[s % n_res], dp)
+    t_host = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
-    log("timed region done: %.3f ms/step" % (dt / args.steps * 1e3))
+    log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (dt / args.steps * 1e3,
+                                                                        t_host / args.steps * 1e3))
     prof, ops.PROFILE = ops.PROFILE, None
     if world > 1:
         import torch.distributed as dist

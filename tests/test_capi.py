@@ -48,7 +48,7 @@ def test_workspace_size_queries():
     assert lib.xdfm_cin_fwd_pack_elems(128, 128, 26) == 1 * (128 * 13 + 4) * 64 * 4
     assert lib.xdfm_cin_fwd_pack_elems(256, 26, 26) == 1 * (340 + 4) * 64 * 8
     assert lib.xdfm_cin_fwd_pack_elems(512, 26, 22) == 2 * (288 + 4) * 64 * 8
-    assert lib.xdfm_cin_bwd_pack_elems(128, 128, 26) == (4 * 26 * 16 + 3) * 256
+    assert lib.xdfm_cin_bwd_pack_elems(128, 128, 26) == (4 * 26 * 16 + 2 * 16 + 3) * 256
     assert lib.xdfm_cin_bwd_pack_elems(300, 4, 4) == 0          # > 256 rows per call is rejected
     # one dWt copy per n-split: (L2 of config 2: 7 workgroups per split -> 73 splits of 928 columns)
     assert lib.xdfm_cin_bwd_w_ws_elems(128, 64, 26, 65536) == 26 * 128 * 64 * 71

@@ -99,7 +99,9 @@ __global__ void cin_bwd_pack_kernel(const float* __restrict__ W, int H, int Hp, 
     Wz[idx] = v;
 }
 
-template <int HS4>
+// JB = number of (i-block, j) chains a wave runs interleaved (independent accumulators).  JB = 2 needs an
+// even m (chains are paired (j, j+1)) and 32 more VGPRs.
+template <int HS4, int JB>
 __global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
     const float* __restrict__ dOut, const float* xp, const float* x0, const float* __restrict__ Wz,
     int H, int Hp, int m, long N, int IB, float* dxp, float* dx0) {
@@ -127,12 +129,17 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
         breg[q] = v * ((h < H) ? nmask : 0.f);
     }
 
-    constexpr int R = HS4 >= 4 ? 4 : HS4;      // ring of float4 A groups
+    constexpr int R = HS4 >= 4 ? 4 : HS4;      // ring of float4 A groups per chain
     constexpr int PD = R - 1;
     const f32x4* ap = reinterpret_cast<const f32x4*>(Wz) + lane;
-    f32x4 ring[R];
+    // group index of ring position q of chain b, relative to the first group g of the current chain set:
+    // positions past the end of a chain belong to the same chain of the NEXT set (JB chains further on)
+    auto gidx = [](int b, int q) { return q < HS4 ? b * HS4 + q : (JB + b) * HS4 + (q - HS4); };
+    f32x4 ring[JB][R];
 #pragma unroll
-    for (int k = 0; k < PD; ++k) ring[k] = ap[(long)k * 64];
+    for (int b = 0; b < JB; ++b)
+#pragma unroll
+        for (int k = 0; k < PD; ++k) ring[b][k] = ap[(long)gidx(b, k) * 64];
     long g = 0;
 
     for (int iblk = 0; iblk < IB; ++iblk) {
@@ -144,33 +151,41 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
             xpr[r] = v * ((i < Hp) ? nmask : 0.f);
             dxa[r] = 0.f;
         }
-        for (int j = 0; j < m; ++j) {
-            const float x0j = x0[(long)j * N + nc] * nmask;    // consumed after the chain
-            f32x16 acc;
+        for (int j = 0; j < m; j += JB) {
+            float x0j[JB];                                   // consumed after the chains
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int b = 0; b < JB; ++b) x0j[b] = x0[(long)(j + b) * N + nc] * nmask;
+            f32x16 acc[JB];
+#pragma unroll
+            for (int b = 0; b < JB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
 #pragma unroll
             for (int q4 = 0; q4 < HS4; ++q4) {
-                ring[(q4 + PD) % R] = ap[(g + q4 + PD) * 64];
-                const f32x4 av = ring[q4 % R];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], breg[4 * q4 + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], breg[4 * q4 + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], breg[4 * q4 + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], breg[4 * q4 + 3], acc, 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < JB; ++b) ring[b][(q4 + PD) % R] = ap[(g + gidx(b, q4 + PD)) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int b = 0; b < JB; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[b][q4 % R][e], breg[4 * q4 + e], acc[b], 0, 0, 0);
                 // pin the order: without this hipcc sinks every ring load down to its first use
                 // (one register quad, vmcnt(0) before each group) and the prefetch distance is lost
                 __builtin_amdgcn_sched_barrier(0);
             }
-            g += HS4;
-            // acc[r] = dZ[(i = iblk*32 + frag_row(r,s), j)][n]
-            float sj = 0.f;
+            g += JB * HS4;
+            // acc[b][r] = dZ[(i = iblk*32 + frag_row(r,s), j + b)][n]
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dxa[r] = fmaf(acc[r], x0j, dxa[r]);
-                sj = fmaf(acc[r], xpr[r], sj);
+            for (int b = 0; b < JB; ++b) {
+                float sj = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dxa[r] = fmaf(acc[b][r], x0j[b], dxa[r]);
+                    sj = fmaf(acc[b][r], xpr[r], sj);
+                }
+                sj += __shfl_xor(sj, 32);
+                if (s == 0) dx0s[(j + b) * 32 + c] += sj;
             }
-            sj += __shfl_xor(sj, 32);
-            if (s == 0) dx0s[j * 32 + c] += sj;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
             if (i < Hp && nok) dxp[(long)i * N + n] += dxa[r];
         }
     }
-    // flush the wave's dx0 slice (dxp may alias dx0 for level 0: same wave, program order)
+    // flush the wave's dx0 slice
     for (int idx = lane; idx < m * 32; idx += 64) {
         const int j = idx >> 5;
         const long nn = n0 + (idx & 31);
@@ -667,8 +682,14 @@ static int launch_bwd_x(const float* dOut, const float* xp, const float* x0, con
     size_t lds = (size_t)4 * m * 32 * sizeof(float);
     if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds);
     if (xdfm_opt(OPT_DBG) & 4) lds = 80 * 1024;
-    hipLaunchKernelGGL((cin_bwd_x_kernel<HS4>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, Wz, H,
-                       Hp, m, N, IB, dxp, dx0);
+    // optional: two interleaved chains per wave (even m, H <= 128).  Measured 110 vs 112 TFLOP/s for the
+    // single dependent chain at config 2, so it stays off by default (A/B knob: dbg bit 5).
+    if (HS4 <= 16 && HS4 >= 4 && m % 2 == 0 && (xdfm_opt(OPT_DBG) & 32))
+        hipLaunchKernelGGL((cin_bwd_x_kernel<HS4, 2>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, Wz, H,
+                           Hp, m, N, IB, dxp, dx0);
+    else
+        hipLaunchKernelGGL((cin_bwd_x_kernel<HS4, 1>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, Wz, H,
+                           Hp, m, N, IB, dxp, dx0);
     return xdfm_check_launch("cin_level_bwd_x");
 }
 
@@ -758,7 +779,7 @@ int xdfm_cin_dout(const float* A, int H, int B, int D, int act, const float* dHi
 
 size_t xdfm_cin_bwd_pack_elems(int H, int Hp, int m) {
     if (H <= 0 || Hp <= 0 || m <= 0 || H > 256) return 0;
-    return ((size_t)ceil_div(Hp, 32) * m * bwx_hs4(H) + BWX_PD) * 256;
+    return ((size_t)ceil_div(Hp, 32) * m * bwx_hs4(H) + BWX_TAIL(bwx_hs4(H))) * 256;
 }
 
 int xdfm_cin_bwd_pack(const float* W, int H, int Hp, int m, float* Wz, void* stream) {
@@ -766,7 +787,7 @@ int xdfm_cin_bwd_pack(const float* W, int H, int Hp, int m, float* Wz, void* str
     XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0, "cin_bwd_pack: bad shape H=%d (<=256) Hp=%d m=%d", H, Hp, m);
     const int HS4 = bwx_hs4(H);
     const long real_groups = (long)ceil_div(Hp, 32) * m * HS4;
-    const long total = (real_groups + BWX_PD) * 256;
+    const long total = (real_groups + BWX_TAIL(HS4)) * 256;
     hipLaunchKernelGGL(cin_bwd_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, W, H, Hp,
                        m, HS4, total, real_groups, Wz);
     return xdfm_check_launch("cin_bwd_pack");

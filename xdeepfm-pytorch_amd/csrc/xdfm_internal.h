@@ -45,6 +45,9 @@ static inline int fwd_mt(int H) {
 }
 #define FWD_PD 3          // A-fragment prefetch distance in k-steps (ring of 4)
 #define BWX_PD 3          // A-group prefetch distance in the dX kernel (ring of 4 float4)
+// zero groups appended to the packed W^T stream: the ring of a wave that runs 2 chains looks ahead into
+// the same chain of the next chain pair, i.e. up to 2*HS4 + PD groups past the last real one
+#define BWX_TAIL(hs4) (2 * (hs4) + BWX_PD)
 static inline int fwd_mp(int m) { return (m + 1) / 2; }                       // j-pairs per i
 static inline long fwd_tpad(int Hp, int m) { return round_up((long)Hp * fwd_mp(m), 4); }
 static inline int bwx_hs4(int H) {      // float4 groups along the contraction (h) axis
