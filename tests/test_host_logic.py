@@ -146,3 +146,30 @@ def test_epoch_order_reproduces_dataloader_batches():
             got.append([rows[i:i + bs].view(-1).tolist() for i in range(0, n, bs)])
         assert got == want
         assert torch.equal(torch.rand(3), tail_ref)
+
+
+def test_entry_point_reader_and_preprocessor(tmp_path):
+    """xdftrain_amd.py host pieces: Criteo-format reader (tab / comma, header or not, blanks) and the
+    unknown->0 / first-appearance->1..N encoder + min-max scaler (xdftrain.py:165-237 semantics)."""
+    import importlib.util
+    import os
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("xdftrain_amd", os.path.join(PKG, "xdftrain_amd.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows = [["1"] + [str(i) for i in range(13)] + ["a%d" % (k % 3) for k in range(26)],
+            ["0"] + ["" if i == 2 else str(2 * i) for i in range(13)] + ["b"] * 25 + [""],
+            ["1"] + [str(i + 5) for i in range(13)] + ["a0"] * 26]
+    p = tmp_path / "train.txt"
+    p.write_text("\n".join("\t".join(r) for r in rows) + "\n")
+    t = mod.read_table(str(p))
+    assert t["label"].tolist() == [1.0, 0.0, 1.0] and t["I3"][1] == 0.0 and t["C26"][1] == "-1"
+    hdr = tmp_path / "hdr.csv"
+    hdr.write_text(",".join(["label"] + mod.DENSE + mod.SPARSE) + "\n" + "\n".join(",".join(r) for r in rows) + "\n")
+    t2 = mod.read_table(str(hdr))
+    assert t2["label"].tolist() == t["label"].tolist() and list(t2["C1"]) == list(t["C1"])
+    prep = mod.Preprocessor().fit(mod.take(t, np.array([0, 1])))
+    x = prep.transform(t)
+    assert x["C1"].tolist() == [1, 2, 1] and x["C2"].tolist() == [1, 2, 0]      # "a0" unseen for C2 -> 0
+    assert prep.vocab("C1") == 3 and x["I2"].dtype == np.float32
+    assert x["I2"][0] == 0.0 and x["I2"][1] == 1.0 and abs(x["I2"][2] - 5.0) < 1e-6   # (6 - 1) / (2 - 1): scaled with the fit range

@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Criteo-format training entry point on the MI355X path.
+
+Takes the command-line flags of the reference's xdftrain.py / xdftrain_attn.py
+(`xdftrain.py:707-738`, `xdftrain_attn.py:736-760`) and follows their `--mode eval` flow
+(`xdftrain.py:302-550`): read label + I1..I13 + C1..C26, encode categories (unknown -> 0, known ->
+1..N in order of first appearance), min-max scale the dense columns, build `SparseFeat` / `DenseFeat`
+columns, `compile`, `fit` with optional EarlyStopping / ModelCheckpoint, `predict`, and write
+`history.json`, `xdeepfm_weights.pth`, `test_predictions.csv`, `preprocess.json`.  The reference's
+own scripts also run unchanged against the `deepctr` package next to this file (they additionally
+need pandas / sklearn / tensorboard); this script has no such dependencies beyond numpy + torch and
+adds `--synthetic N` (no data file needed) and multi-process launch:
+
+    python xdftrain_amd.py --synthetic 200000 --epochs 2 --embedding_dim 16
+    python -m torch.distributed.run --nproc-per-node 8 xdftrain_amd.py --data_path train.txt ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from deepctr.callbacks import EarlyStopping, ModelCheckpoint  # noqa: E402
+from deepctr.inputs import DenseFeat, SparseFeat, get_feature_names  # noqa: E402
+from deepctr import models  # noqa: E402
+from xdfm_amd import metrics as M  # noqa: E402
+
+SPARSE = ["C%d" % i for i in range(1, 27)]
+DENSE = ["I%d" % i for i in range(1, 14)]
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--data_path", type=str, default=None)
+    p.add_argument("--eval_path", type=str, default=None)
+    p.add_argument("--test_path", type=str, default=None)
+    p.add_argument("--synthetic", type=int, default=0, help="generate this many Criteo-shaped rows instead of reading a file")
+    p.add_argument("--out_dir", type=str, default="./outputs_xdeepfm")
+    p.add_argument("--device", type=str, default="cuda:0")
+    p.add_argument("--seed", type=int, default=2025)
+    p.add_argument("--model", type=str, default="xdeepfm", choices=["xdeepfm", "attn"])
+    p.add_argument("--model_version", type=str, default="v1", choices=["v1", "v2"])
+    p.add_argument("--embedding_dim", type=int, default=10)
+    p.add_argument("--cin_layer_size", type=str, default="256,128")
+    p.add_argument("--dnn_hidden_units", type=str, default="256,256")
+    p.add_argument("--cin_num_heads", type=int, default=4)
+    p.add_argument("--cin_no_layer_norm", action="store_false", dest="cin_use_layer_norm")
+    p.add_argument("--cin_no_residual", action="store_false", dest="cin_use_residual")
+    p.add_argument("--cin_num_attn_layers", type=int, default=1)
+    p.add_argument("--l2_reg_embedding", type=float, default=1e-5)
+    p.add_argument("--l2_reg_dnn", type=float, default=1e-5)
+    p.add_argument("--dnn_dropout", type=float, default=0.0)
+    p.add_argument("--learning_rate", type=float, default=0.001)
+    p.add_argument("--optimizer", type=str, default="adam", choices=["adam", "adagrad", "sgd"])
+    p.add_argument("--epochs", type=int, default=3)
+    p.add_argument("--batch_size", type=int, default=4096)
+    p.add_argument("--pred_batch_size", type=int, default=8192)
+    p.add_argument("--val_size", type=float, default=0.1)
+    p.add_argument("--use_early_stopping", action="store_true")
+    p.add_argument("--patience", type=int, default=50)
+    p.add_argument("--verbose", type=int, default=2, choices=[0, 1, 2])
+    return p.parse_args()
+
+
+def read_table(path, with_label=True):
+    """label, I1..I13, C1..C26 separated by tab or comma, optional header row; '' -> missing."""
+    names = (["label"] if with_label else []) + DENSE + SPARSE
+    with open(path, "r", encoding="utf-8", errors="ignore") as f:
+        first = f.readline()
+        second = f.readline()
+    sep = "\t" if "\t" in (second or first) else ","
+    has_header = not first.split("\t" if "\t" in first else ",")[0].strip().lstrip("-").replace(".", "").isdigit()
+    cols = {n: [] for n in names}
+    with open(path, "r", encoding="utf-8", errors="ignore") as f:
+        if has_header:
+            f.readline()
+        for line in f:
+            parts = line.rstrip("\n").split(sep)
+            if len(parts) < len(names):
+                parts += [""] * (len(names) - len(parts))
+            for n, v in zip(names, parts):
+                cols[n].append(v)
+    out = {}
+    for n in names:
+        if n in SPARSE:
+            out[n] = np.array([v if v != "" else "-1" for v in cols[n]], dtype=object)
+        else:
+            out[n] = np.array([float(v) if v != "" else 0.0 for v in cols[n]], dtype=np.float64)
+    return out
+
+
+def synthetic_table(n, seed):
+    """Criteo-shaped rows whose label depends on a few categorical ids and dense values (learnable)."""
+    rng = np.random.default_rng(seed)
+    out, logit = {}, np.full(n, -1.6)
+    for k, name in enumerate(DENSE):
+        out[name] = np.floor(rng.gamma(1.0 + 0.3 * k, 20.0, n))
+        if k < 4:
+            logit += 0.25 * rng.normal() * np.log1p(out[name]) / 3.0
+    for k, name in enumerate(SPARSE):
+        vocab = 50 + 4000 * (k % 7)
+        ids = np.floor(vocab * rng.random(n) ** 3).astype(np.int64)
+        out[name] = np.array(["%x" % v for v in ids], dtype=object)
+        if k % 7 == 0:                                   # the small-vocabulary fields carry signal
+            logit += rng.normal(0.0, 0.8, vocab)[ids]
+    out["label"] = (rng.random(n) < 1.0 / (1.0 + np.exp(-logit))).astype(np.float64)
+    return out
+
+
+class Preprocessor(object):
+    """Category ids: 0 = unseen, 1..N in order of first appearance in the training split; dense columns
+    min-max scaled to [0, 1] with the training split's range (the reference's SafeLabelEncoder + MinMaxScaler)."""
+
+    def fit(self, table):
+        self.maps, self.lo, self.hi = {}, {}, {}
+        for n in SPARSE:
+            seen = {}
+            for v in table[n]:
+                if v not in seen:
+                    seen[v] = len(seen) + 1
+            self.maps[n] = seen
+        for n in DENSE:
+            self.lo[n], self.hi[n] = float(np.min(table[n])), float(np.max(table[n]))
+        return self
+
+    def transform(self, table):
+        out = {}
+        for n in SPARSE:
+            mp = self.maps[n]
+            out[n] = np.fromiter((mp.get(v, 0) for v in table[n]), dtype=np.int64, count=len(table[n]))
+        for n in DENSE:
+            span = self.hi[n] - self.lo[n]
+            out[n] = ((table[n] - self.lo[n]) / (span if span > 0 else 1.0)).astype(np.float32)
+        return out
+
+    def vocab(self, n):
+        return len(self.maps[n]) + 1
+
+
+def take(table, idx):
+    return {k: v[idx] for k, v in table.items()}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        args.device = "cuda:%d" % local
+        dist.init_process_group("nccl", device_id=torch.device(args.device))
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    os.makedirs(args.out_dir, exist_ok=True)
+    t0 = time.time()
+
+    if args.synthetic > 0:
+        table = synthetic_table(args.synthetic, args.seed)
+    elif args.data_path:
+        table = read_table(args.data_path)
+    else:
+        raise SystemExit("give --data_path or --synthetic N")
+    n = len(table["label"])
+    if args.eval_path:
+        train_t, val_t = table, read_table(args.eval_path)
+    else:
+        perm = np.random.default_rng(args.seed).permutation(n)
+        n_val = int(round(n * args.val_size))
+        train_t, val_t = take(table, perm[n_val:]), take(table, perm[:n_val])
+    prep = Preprocessor().fit(train_t)
+    xtr, xva = prep.transform(train_t), prep.transform(val_t)
+
+    cols = [SparseFeat(f, vocabulary_size=prep.vocab(f), embedding_dim=args.embedding_dim) for f in SPARSE]
+    cols += [DenseFeat(f, 1) for f in DENSE]
+    names = get_feature_names(cols + cols)
+    cin = tuple(int(v) for v in args.cin_layer_size.split(","))
+    dnn = tuple(int(v) for v in args.dnn_hidden_units.split(","))
+    common = dict(dnn_hidden_units=dnn, cin_layer_size=cin, task="binary", l2_reg_embedding=args.l2_reg_embedding,
+                  l2_reg_dnn=args.l2_reg_dnn, dnn_dropout=args.dnn_dropout, device=args.device)
+    if args.model == "xdeepfm":
+        model = models.xDeepFM(cols, cols, **common)
+    else:
+        kw = dict(cin_num_heads=args.cin_num_heads, cin_use_layer_norm=args.cin_use_layer_norm,
+                  cin_use_residual=args.cin_use_residual)
+        if args.model_version == "v1":
+            model = models.xDeepFMAttention(cols, cols, **common, **kw)
+        else:
+            model = models.xDeepFMAttentionV2(cols, cols, cin_num_attn_layers=args.cin_num_attn_layers, **common, **kw)
+    model.compile(optimizer=args.optimizer, loss="binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+    for pg in model.optim.param_groups:
+        pg["lr"] = args.learning_rate
+
+    best = os.path.join(args.out_dir, "best_model.pth")
+    cbs = [ModelCheckpoint(best, monitor="val_auc", save_best_only=True, save_weights_only=True, mode="max", verbose=0)]
+    if args.use_early_stopping:
+        cbs.append(EarlyStopping(monitor="val_auc", patience=args.patience, mode="max", verbose=1))
+    hist = model.fit({k: xtr[k] for k in names}, train_t["label"], batch_size=args.batch_size, epochs=args.epochs,
+                     verbose=args.verbose, validation_data=({k: xva[k] for k in names}, val_t["label"]),
+                     shuffle=True, callbacks=cbs)
+    if rank == 0:
+        if os.path.exists(best):
+            model.load_state_dict(torch.load(best, weights_only=True))
+        pred = model.predict({k: xva[k] for k in names}, args.pred_batch_size)
+        print("[RESULT] val logloss %.6f  val AUC %.6f  (%.1f s)" % (
+            M.log_loss(val_t["label"], pred), M.roc_auc_score(val_t["label"], pred), time.time() - t0))
+        if args.test_path:
+            xte = prep.transform(read_table(args.test_path, with_label=False))
+            tp = model.predict({k: xte[k] for k in names}, args.pred_batch_size)
+            np.savetxt(os.path.join(args.out_dir, "test_predictions.csv"), tp, header="prediction", comments="")
+        torch.save(model.state_dict(), os.path.join(args.out_dir, "xdeepfm_weights.pth"))
+        json.dump({k: [float(v) for v in vals] for k, vals in hist.history.items()},
+                  open(os.path.join(args.out_dir, "history.json"), "w"), indent=1)
+        json.dump({"vocab": {f: prep.vocab(f) for f in SPARSE}, "dense_min": prep.lo, "dense_max": prep.hi},
+                  open(os.path.join(args.out_dir, "preprocess.json"), "w"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
