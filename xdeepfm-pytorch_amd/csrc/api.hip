@@ -9,8 +9,9 @@ static int g_opts[OPT_COUNT] = {
     /* OPT_BWW_SLAB */ 1,
     /* OPT_BWW_MT */ 0,
     /* OPT_DBG */ 0,
+    /* OPT_CIN_MATH */ 0,
 };
-static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg"};
+static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math"};
 
 int xdfm_fail(int code, const char* fmt, ...) {
     va_list ap;

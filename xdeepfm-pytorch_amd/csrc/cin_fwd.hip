@@ -400,6 +400,7 @@ extern "C" {
 
 size_t xdfm_cin_fwd_pack_elems(int H, int Hp, int m) {
     if (H <= 0 || Hp <= 0 || m <= 0) return 0;
+    if (x3_fwd_usable(H, Hp, m)) return x3_fwd_pack_elems(H, Hp, m);
     const int MT = fwd_mt(H);
     return (size_t)ceil_div(H, 32 * MT) * (size_t)(fwd_tpad(Hp, m) + 4) * 64 * MT;
 }
@@ -408,6 +409,7 @@ int xdfm_cin_fwd_pack(const float* W, int H, int Hp, int m, float* Wf, void* str
     XDFM_REQUIRE(W && Wf, "cin_fwd_pack: null pointer");
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0, "cin_fwd_pack: bad shape H=%d Hp=%d m=%d", H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
+    if (x3_fwd_usable(H, Hp, m)) return x3_fwd_pack(W, H, Hp, m, Wf, st);
     switch (fwd_mt(H)) {
         case 1: return launch_pack<1>(W, H, Hp, m, Wf, st);
         case 2: return launch_pack<2>(W, H, Hp, m, Wf, st);
@@ -422,6 +424,7 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_fwd: bad shape H=%d Hp=%d m=%d N=%ld", H, Hp, m, N);
     XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_level_fwd: unsupported activation %d", act);
     hipStream_t st = (hipStream_t)stream;
+    if (x3_fwd_usable(H, Hp, m)) return x3_level_fwd(xp, x0, Wf, bias, H, Hp, m, N, act, out, st);
     const int nf = xdfm_opt(OPT_FWD_NF) == 2 ? 2 : 1;
     switch (fwd_mt(H)) {
         case 1: return launch_fwd<1, 1>(xp, x0, Wf, bias, H, Hp, m, N, act, out, st);

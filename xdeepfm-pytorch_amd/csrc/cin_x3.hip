@@ -1,0 +1,305 @@
+// f16x3 arithmetic for the CIN contraction (option "cin_math" = 1): fp32 operands are split on the fly
+// into two fp16 halves (x = hi + lo, 22 mantissa bits) and every fp32 product is formed by THREE
+// v_mfma_f32_32x32x16_f16 (hi*hi + hi*lo + lo*hi) accumulated in fp32.  The dropped lo*lo term is 2^-22
+// relative, i.e. below the rounding of the fp32 accumulation itself over K = Hp*m terms: against an fp64
+// GEMM this path measures the same (slightly smaller) error as the plain fp32 MFMA path
+// (tests/test_gpu_parity.py::test_cin_x3_*).  The matrix pipe runs 16 k per 32 cycles instead of 2 k per
+// 64 cycles, so three MFMAs per product are still 5.3x the fp32 MFMA rate.
+//
+// fp16 has a 5-bit exponent, so operands are range-fitted with exact power-of-two scales that are
+// removed from the fp32 accumulator in the epilogue: one scale for the weight matrix (|W| <  2^15) and
+// one per column n for x0[:, n] and x_prev[:, n] (|Z| < 2^14).  Elements more than 2^18 below their
+// column's maximum lose relative precision but keep an absolute error of 2^-40 of that maximum.
+//
+// This file: the forward kernel (K3) and its weight pack.  deepctr/layers/interaction.py:218-229.
+#include <type_traits>
+#include "xdfm_internal.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// ---------------------------------------------------------------------------------------------
+// geometry shared by pack and kernel.  The contraction index k = (i, j) is walked in blocks of 8 rows
+// i of x_prev: lane half hh (= lane >> 5) owns rows blk*8 + hh*RH + il, il < RH (RH = 4; in the ragged
+// last block RH = ceil(rows_left / 2)).  Inside a block, MFMA step s covers the flat positions
+// q = 8s .. 8s+7 of the half's (il, j) list, q = il*m + j, so with an even m both halves run the same
+// compile-time (il, j) pattern and only their x_prev rows differ.
+X3Geom x3_fwd_geom(int H, int Hp, int m) {
+    X3Geom g;
+    const int t = ceil_div(H, 32);
+    g.MT = t >= 8 ? 8 : (t > 2 ? 4 : 2);
+    g.MB = ceil_div(H, 32 * g.MT);
+    g.MP = m / 2;
+    g.FB = Hp / 8;
+    const int R = Hp - 8 * g.FB;
+    g.RH = (R + 1) / 2;
+    g.TS = ceil_div(g.RH * m, 8);
+    g.NS = g.FB * g.MP + g.TS;
+    return g;
+}
+
+bool x3_fwd_usable(int H, int Hp, int m) {
+    (void)Hp;
+    return xdfm_opt(OPT_CIN_MATH) == 1 && (m == 26 || m == 22) && H > 32;
+}
+
+// power of two s with amax*s in [2^(target-1), 2^target); 1 for amax == 0 or denormal
+__device__ __forceinline__ float x3_pow2_scale(float amax, int target) {
+    const int E = (int)((__float_as_uint(amax) >> 23) & 0xff);
+    int be = 253 + target - E;
+    be = be < 1 ? 1 : (be > 253 ? 253 : be);
+    return E == 0 ? 1.f : __uint_as_float((unsigned)be << 23);
+}
+
+__device__ __forceinline__ void x3_split2(float z0, float z1, h2& hi, h2& lo) {
+    const f2 z = {z0, z1};
+    hi = __builtin_convertvector(z, h2);                 // v_cvt_pk_f16_f32 (RNE)
+    const f2 r = {z0 - (float)hi.x, z1 - (float)hi.y};   // exact in fp32
+    lo = __builtin_convertvector(r, h2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// |W| maximum -> header slot 2 (as uint bits; non-negative floats order like their bit patterns)
+__global__ void x3_absmax_kernel(const float* __restrict__ W, long total, unsigned* __restrict__ hdr) {
+    float v = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        v = fmaxf(v, fabsf(W[i]));
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(hdr + 2, __float_as_uint(v));
+}
+
+// pack layout (after the X3_HDR-float header: [0] = sW, [1] = 1/sW, [2] = max|W| bits):
+//   [mb][g < NS+2][mt < MT][p: 0 = hi, 1 = lo][lane][8 halves]   -- 1 KB per (mt, p) fragment
+// element t of lane (r = lane & 31, hh = lane >> 5) of step g = (blk, s):
+//   row = (mb*MT + mt)*32 + r,  q = 8s + t,  il = q / m,  j = q % m,  i = blk*8 + hh*RH + il
+__global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3Geom G,
+                                   float* __restrict__ pack) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)G.MB * (G.NS + 2) * G.MT * 64;
+    if (idx >= total) return;
+    const float sW = x3_pow2_scale(pack[2], 15);
+    if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
+    const int lane = (int)(idx & 63);
+    long rest = idx >> 6;
+    const int mt = (int)(rest % G.MT); rest /= G.MT;
+    const int g = (int)(rest % (G.NS + 2));
+    const int mb = (int)(rest / (G.NS + 2));
+    const int r = lane & 31, hh = lane >> 5;
+    const int row = (mb * G.MT + mt) * 32 + r;
+    int blk, s, RH;
+    if (g < G.FB * G.MP) { blk = g / G.MP; s = g - blk * G.MP; RH = 4; }
+    else { blk = G.FB; s = g - G.FB * G.MP; RH = G.RH; }
+    h8 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = 8 * s + t, il = q / m, j = q - il * m;
+        const int i = blk * 8 + hh * RH + il;
+        float v = 0.f;
+        if (g < G.NS && row < H && il < RH && i < Hp) v = W[(long)row * ((long)Hp * m) + (long)i * m + j] * sW;
+        const _Float16 a = (_Float16)v;
+        hi[t] = a;
+        lo[t] = (_Float16)(v - (float)a);
+    }
+    h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (((long)mb * (G.NS + 2) + g) * G.MT + mt) * 128 + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward kernel.  Workgroup = 4 waves = 128 columns x (32*MT rows of one row group mb); a wave owns
+// 32 columns and all MT row tiles.  The packed weight fragments of one step (2*MT KB) are shared by the
+// four waves through a 3-deep LDS ring filled by 16-byte LDS-DMA two steps ahead (one counted
+// s_waitcnt vmcnt + raw s_barrier per step); each wave builds its own B operand (Z hi / lo) in registers.
+template <int MT, int M>
+__global__ __launch_bounds__(256, 2) void cin_fwd_x3_kernel(
+    const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ pack,
+    const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MP = M / 2;
+    constexpr int FR = 2 * MT;                  // 1-KB fragments per stage
+    constexpr int STAGE = FR * 1024;            // bytes
+    constexpr int FPW = FR / 4;                 // LDS-DMA instructions per wave and stage
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const long n = ((long)blockIdx.x * 4 + wave) * 32 + c;
+    const bool nok = n < N;                     // no early exit: every wave feeds the ring and the barriers
+    const long nc = nok ? n : N - 1;
+    const float nmask = nok ? 1.f : 0.f;
+    const int mb = blockIdx.y;
+
+    const char* wsrc = reinterpret_cast<const char*>(pack + X3_HDR) + (long)mb * (G.NS + 2) * STAGE + lane * 16;
+    auto dma_stage = [&](const char* src, int slot_off) {
+#pragma unroll
+        for (int k = 0; k < FPW; ++k) {
+            const int f = wave * FPW + k;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + f * 1024),
+                                             (LDS_AS void*)(smem + slot_off + f * 1024), 16, 0, 0);
+        }
+    };
+    dma_stage(wsrc, 0);
+    dma_stage(wsrc + STAGE, STAGE);
+
+    // ---- x0 column (registers), column scales --------------------------------------------------
+    float x0r[M];
+    float a0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        x0r[j] = x0[(long)j * N + nc] * nmask;
+        a0 = fmaxf(a0, fabsf(x0r[j]));
+    }
+    float ap = 0.f;
+    if (xp == x0) {
+        ap = a0;
+    } else {
+        for (int i = hh; i < Hp; i += 2) ap = fmaxf(ap, fabsf(xp[(long)i * N + nc]));
+        ap = fmaxf(ap, __shfl_xor(ap, 32)) * nmask;
+    }
+    const float s0 = x3_pow2_scale(a0, 7), sp = x3_pow2_scale(ap, 7);
+#pragma unroll
+    for (int j = 0; j < M; ++j) x0r[j] *= s0;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // x_prev rows of this lane half in block blk: blk*8 + hh*RH + il.  The raw loads are multiplied by
+    // their factor (column scale, or 0 for rows / columns outside the matrix) only where they are first
+    // used, one block later, so nothing waits on them while the ring's DMAs are in flight.
+    auto load_xp = [&](int blk, int RH, float (&v)[4], float (&f)[4]) {
+#pragma unroll
+        for (int il = 0; il < 4; ++il) {
+            const int i = blk * 8 + hh * RH + il;
+            const bool ok = il < RH && i < Hp;
+            v[il] = xp[(long)(ok ? i : 0) * N + nc];
+            f[il] = ok ? sp * nmask : 0.f;
+        }
+    };
+    // B operand (hi, lo) of step s of a block from the block's 4 x_prev values
+    auto build_b = [&](int s, const float (&xv)[4], h8& bh, h8& bl) {
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            const int q = 8 * s + 2 * t2, il = q / M, j = q - il * M;
+            h2 hi, lo;
+            if (il < 4) x3_split2(xv[il] * x0r[j], xv[il] * x0r[j + 1], hi, lo);
+            else { hi = h2{0, 0}; lo = h2{0, 0}; }
+            bh[2 * t2] = hi.x; bh[2 * t2 + 1] = hi.y;
+            bl[2 * t2] = lo.x; bl[2 * t2 + 1] = lo.y;
+        }
+    };
+
+    int so[3] = {0, STAGE, 2 * STAGE};          // LDS offsets of the ring slots of steps s % 3 of this block
+    const int nblk = G.FB + (G.TS > 0 ? 1 : 0);
+    float xv[4], xn[4], fn[4];
+    load_xp(0, G.FB > 0 ? 4 : G.RH, xv, fn);
+#pragma unroll
+    for (int il = 0; il < 4; ++il) xv[il] *= fn[il];
+    h8 bh, bl;
+    build_b(0, xv, bh, bl);
+    const char* wblk = wsrc;
+
+    auto block_steps = [&](int blk, int nsteps_dyn, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const bool has_next = blk + 1 < nblk;
+        if (has_next) load_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn, fn);
+#pragma unroll
+        for (int s = 0; s < MP; ++s) {
+            if (FULL || s < nsteps_dyn) {       // wave-uniform
+            h8 nh = bh, nl = bl;                         // operand of the step after this one, built in its shadow
+            if (s + 1 < MP) {
+                if (FULL || s + 1 < nsteps_dyn) build_b(s + 1, xv, nh, nl);
+            } else if (has_next) {
+#pragma unroll
+                for (int il = 0; il < 4; ++il) xn[il] *= fn[il];
+                build_b(0, xn, nh, nl);
+            }
+            // stage (blk, s) has landed for this wave's pieces; after the barrier for everyone's
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FPW) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            dma_stage(wblk + (s + 2) * STAGE, so[(s + 2) % 3]);
+            const char* st = smem + so[s % 3] + lane * 16;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h8 ah = *reinterpret_cast<const h8*>(st + (2 * mt) * 1024);
+                const h8 al = *reinterpret_cast<const h8*>(st + (2 * mt + 1) * 1024);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mt], 0, 0, 0);
+            }
+            bh = nh; bl = nl;
+            }
+        }
+        // next block: rotate the ring slots by the number of steps taken, first B operand
+        const int adv = FULL ? MP : nsteps_dyn;
+        wblk += (long)adv * STAGE;
+        for (int k = 0; k < adv % 3; ++k) { const int t = so[0]; so[0] = so[1]; so[1] = so[2]; so[2] = t; }
+        if (has_next) {
+#pragma unroll
+            for (int il = 0; il < 4; ++il) xv[il] = xn[il];
+        }
+    };
+    for (int blk = 0; blk < G.FB; ++blk) block_steps(blk, MP, std::true_type{});
+    if (G.TS > 0) block_steps(G.FB, G.TS, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two look-ahead stages must land before LDS is released
+
+    // ---- epilogue: remove the scales, bias + activation, FM-layout store --------------------------
+    const float iW = pack[1], i0 = 1.f / s0, ip = 1.f / sp;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mb * MT + mt) * 32 + frag_row(r, hh);
+            if (row < H && nok) {
+                float v = acc[mt][r] * iW * ip * i0 + bias[row];
+                if (act == XDFM_ACT_RELU) v = fmaxf(v, 0.f);
+                out[(long)row * N + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t x3_fwd_pack_elems(int H, int Hp, int m) {
+    const X3Geom g = x3_fwd_geom(H, Hp, m);
+    return (size_t)X3_HDR + (size_t)g.MB * (g.NS + 2) * g.MT * 512;       // 2 KB = 512 floats per (step, row tile)
+}
+
+int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
+    const X3Geom g = x3_fwd_geom(H, Hp, m);
+    hipError_t e = hipMemsetAsync(pack, 0, X3_HDR * sizeof(float), st);
+    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_fwd_pack memset: %s", hipGetErrorString(e));
+    const long total = (long)H * Hp * m;
+    hipLaunchKernelGGL(x3_absmax_kernel, dim3(ceil_div(total, 256 * 8) > 1024 ? 1024 : ceil_div(total, 256 * 8)), dim3(256),
+                       0, st, W, total, reinterpret_cast<unsigned*>(pack));
+    const long threads = (long)g.MB * (g.NS + 2) * g.MT * 64;
+    hipLaunchKernelGGL(x3_fwd_pack_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, st, W, H, Hp, m, g, pack);
+    return xdfm_check_launch("cin_fwd_pack (f16x3)");
+}
+
+template <int MT, int M>
+static int launch_x3(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, long N,
+                     const X3Geom& g, int act, float* out, hipStream_t st) {
+    const size_t lds = (size_t)3 * 2 * MT * 1024;
+    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds, st, xp, x0, pack, bias, H,
+                       Hp, N, g, act, out);
+    return xdfm_check_launch("cin_level_fwd (f16x3)");
+}
+
+int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
+                 int act, float* out, hipStream_t st) {
+    const X3Geom g = x3_fwd_geom(H, Hp, m);
+    if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd: packed weights must be 16-byte aligned");
+#define X3_CASE(MTV, MV) \
+    if (g.MT == MTV && m == MV) return launch_x3<MTV, MV>(xp, x0, pack, bias, H, Hp, N, g, act, out, st);
+    X3_CASE(2, 26) X3_CASE(4, 26) X3_CASE(8, 26)
+    X3_CASE(2, 22) X3_CASE(4, 22) X3_CASE(8, 22)
+#undef X3_CASE
+    return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd (f16x3): no kernel for MT=%d m=%d", g.MT, m);
+}

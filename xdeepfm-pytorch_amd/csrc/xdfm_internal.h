@@ -19,6 +19,7 @@ enum {
     OPT_BWW_SLAB,        // 1 (default) = per-split slabs + ordered sum (deterministic); 0 = fp32 atomics
     OPT_BWW_MT,          // 0 = auto; 1/2/4 = row tiles (of 32) per wave in the dW kernel
     OPT_DBG,             // timing experiments only (results become wrong): bit0 = A operand from one cached line
+    OPT_CIN_MATH,        // 0 = v_mfma_f32_32x32x2_f32 on fp32 operands; 1 = f16x3 split (cin_x3*.hip) where a kernel exists
     OPT_COUNT
 };
 
@@ -60,3 +61,17 @@ static inline int bwx_hs4(int H) {      // float4 groups along the contraction (
 // C/D fragment of v_mfma_f32_32x32x2_f32: register r of lane (c = lane&31, s = lane>>5)
 // holds element [row = (r&3) + 8*(r>>2) + 4*s][col = c].
 __device__ __forceinline__ int frag_row(int r, int s) { return (r & 3) + 8 * (r >> 2) + 4 * s; }
+
+// ---- f16x3 path (cin_x3*.hip) ------------------------------------------------------------------
+#define X3_HDR 64         // floats in front of a packed weight stream: [0] scale, [1] 1/scale, [2] max|W| bits
+struct X3Geom {
+    int MT, MB;           // row tiles (of 32) per wave, row groups (blockIdx.y)
+    int MP;               // MFMA steps per full block of 8 x_prev rows (= m / 2)
+    int FB, RH, TS, NS;   // full blocks, rows per lane half / steps of the ragged last block, total steps
+};
+X3Geom x3_fwd_geom(int H, int Hp, int m);
+bool x3_fwd_usable(int H, int Hp, int m);
+size_t x3_fwd_pack_elems(int H, int Hp, int m);
+int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
+int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
+                 int act, float* out, hipStream_t st);
