@@ -779,12 +779,14 @@ int xdfm_cin_dout(const float* A, int H, int B, int D, int act, const float* dHi
 
 size_t xdfm_cin_bwd_pack_elems(int H, int Hp, int m) {
     if (H <= 0 || Hp <= 0 || m <= 0 || H > 256) return 0;
+    if (x3_bwx_usable(H, Hp, m)) return x3_bwx_pack_elems(H, Hp, m);
     return ((size_t)ceil_div(Hp, 32) * m * bwx_hs4(H) + BWX_TAIL(bwx_hs4(H))) * 256;
 }
 
 int xdfm_cin_bwd_pack(const float* W, int H, int Hp, int m, float* Wz, void* stream) {
     XDFM_REQUIRE(W && Wz, "cin_bwd_pack: null pointer");
     XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0, "cin_bwd_pack: bad shape H=%d (<=256) Hp=%d m=%d", H, Hp, m);
+    if (x3_bwx_usable(H, Hp, m)) return x3_bwx_pack(W, H, Hp, m, Wz, (hipStream_t)stream);
     const int HS4 = bwx_hs4(H);
     const long real_groups = (long)ceil_div(Hp, 32) * m * HS4;
     const long total = (real_groups + BWX_TAIL(HS4)) * 256;
@@ -799,6 +801,7 @@ int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, co
     XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_x: bad shape H=%d (<=256) Hp=%d m=%d",
                  H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
+    if (x3_bwx_usable(H, Hp, m)) return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
     switch (bwx_hs4(H)) {
         case 1: return launch_bwd_x<1>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
         case 2: return launch_bwd_x<2>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);

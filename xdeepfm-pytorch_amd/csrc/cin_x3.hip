@@ -303,3 +303,213 @@ int x3_level_fwd(const float* xp, const float* x0, const float* pack, const floa
 #undef X3_CASE
     return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd (f16x3): no kernel for MT=%d m=%d", g.MT, m);
 }
+
+// =============================================================================================
+// dX (K4a) in f16x3 arithmetic.   dZ[(i,j)][n] = sum_h W[h][(i,j)] * dOut[h][n]   (never stored)
+//   dxp[i][n] += sum_j dZ * x0[j][n],   dx0[j][n] += sum_i dZ * xp[i][n]
+// GEMM tile: 32 rows i (one i-block) x 32 columns for a fixed j, contraction over h in blocks of 16.
+// B operand = the wave's 32 columns of dOut for ALL h, split into hi / lo once and kept in registers;
+// A operand = packed W^T fragments shared by the 4 waves of the workgroup through the LDS-DMA ring
+// (stage = up to 8 h-blocks = 16 KB = 24 MFMAs per wave).
+// =============================================================================================
+X3BwxGeom x3_bwx_geom(int H, int Hp, int m) {
+    X3BwxGeom g;
+    const int hb = ceil_div(H, 16);
+    g.HBT = hb > 8 ? 16 : (hb > 4 ? 8 : (hb > 2 ? 4 : 2));
+    g.HBS = g.HBT > 8 ? 8 : g.HBT;
+    g.IB = ceil_div(Hp, 32);
+    g.NT = (long)g.IB * m;                              // tiles
+    return g;
+}
+
+bool x3_bwx_usable(int H, int Hp, int m) {
+    (void)Hp; (void)m;
+    return xdfm_opt(OPT_CIN_MATH) == 1 && H > 16 && H <= 256;
+}
+
+// pack: [tile = iblk*m + j][hb < HBT][p][lane][8 halves]; element t of lane (r, hh):
+//   W[h = 16*hb + 8*hh + t][(iblk*32 + r)*m + j] * sW   (0 outside); two dummy stages appended.
+__global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3BwxGeom G, long total,
+                                   float* __restrict__ pack) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float sW = x3_pow2_scale(pack[2], 15);
+    if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
+    const int lane = (int)(idx & 63);
+    long rest = idx >> 6;
+    const int hb = (int)(rest % G.HBT);
+    const long tile = rest / G.HBT;
+    const int j = (int)(tile % m);
+    const int iblk = (int)(tile / m);
+    const int r = lane & 31, hh = lane >> 5;
+    const int i = iblk * 32 + r;
+    h8 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int h = 16 * hb + 8 * hh + t;
+        float v = 0.f;
+        if (tile < G.NT && h < H && i < Hp) v = W[(long)h * ((long)Hp * m) + (long)i * m + j] * sW;
+        const _Float16 a = (_Float16)v;
+        hi[t] = a;
+        lo[t] = (_Float16)(v - (float)a);
+    }
+    h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (tile * G.HBT + hb) * 128 + lane;
+    dst[0] = hi;
+    dst[64] = lo;
+}
+
+template <int HBT>
+__global__ __launch_bounds__(256, 2) void cin_bwd_x3_kernel(
+    const float* __restrict__ dOut, const float* xp, const float* x0, const float* __restrict__ pack,
+    int H, int Hp, int m, long N, int IB, float* dxp, float* dx0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int HBS = HBT > 8 ? 8 : HBT;      // h-blocks per stage
+    constexpr int SPT = HBT / HBS;              // stages per tile
+    constexpr int STAGE = HBS * 2048;
+    constexpr int FPW = HBS * 2 / 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const long n0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const long n = n0 + c;
+    const bool nok = n < N;
+    const long nc = nok ? n : N - 1;
+    const float nmask = nok ? 1.f : 0.f;
+
+    const char* wsrc = reinterpret_cast<const char*>(pack + X3_HDR) + lane * 16;
+    auto dma_stage = [&](const char* src, int slot_off) {
+#pragma unroll
+        for (int k = 0; k < FPW; ++k) {
+            const int f = wave * FPW + k;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + f * 1024),
+                                             (LDS_AS void*)(smem + slot_off + f * 1024), 16, 0, 0);
+        }
+    };
+    dma_stage(wsrc, 0);
+    dma_stage(wsrc + STAGE, STAGE);
+
+    float* x0s = reinterpret_cast<float*>(smem + 3 * STAGE) + wave * (m * 32);     // wave-private x0[j][n0..n0+31]
+    float* dx0s = reinterpret_cast<float*>(smem + 3 * STAGE) + (4 + wave) * (m * 32);
+    for (int idx = lane; idx < m * 32; idx += 64) {
+        const long nn = n0 + (idx & 31);
+        x0s[idx] = x0[(long)(idx >> 5) * N + (nn < N ? nn : N - 1)];
+        dx0s[idx] = 0.f;
+    }
+
+    // B operand: dOut[h][n] for all h of this launch, column-scaled and split, in registers
+    float dmax = 0.f;
+    for (int q = hh; q < H; q += 2) dmax = fmaxf(dmax, fabsf(dOut[(long)q * N + nc]));
+    dmax = fmaxf(dmax, __shfl_xor(dmax, 32)) * nmask;
+    const float sD = x3_pow2_scale(dmax, 15);
+    h8 bh[HBT], bl[HBT];
+#pragma unroll
+    for (int hb = 0; hb < HBT; ++hb) {
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            const int h = 16 * hb + 8 * hh + 2 * t2;
+            const float v0 = dOut[(long)(h < H ? h : H - 1) * N + nc] * ((h < H) ? sD * nmask : 0.f);
+            const float v1 = dOut[(long)(h + 1 < H ? h + 1 : H - 1) * N + nc] * ((h + 1 < H) ? sD * nmask : 0.f);
+            h2 hi, lo;
+            x3_split2(v0, v1, hi, lo);
+            bh[hb][2 * t2] = hi.x; bh[hb][2 * t2 + 1] = hi.y;
+            bl[hb][2 * t2] = lo.x; bl[hb][2 * t2 + 1] = lo.y;
+        }
+    }
+    const float inv = (1.f / sD) * pack[1];      // removes both scales from dZ
+
+    int so0 = 0, so1 = STAGE, so2 = 2 * STAGE;   // ring slot of the current stage, +1, +2
+    const char* wcur = wsrc;
+    for (int iblk = 0; iblk < IB; ++iblk) {
+        float xpr[16], dxa[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = iblk * 32 + frag_row(r, hh);
+            xpr[r] = xp[(long)(i < Hp ? i : Hp - 1) * N + nc] * ((i < Hp) ? nmask : 0.f);
+            dxa[r] = 0.f;
+        }
+        for (int j = 0; j < m; ++j) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < SPT; ++st) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FPW) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                dma_stage(wcur + 2 * STAGE, so2);
+                const char* sp = smem + so0 + lane * 16;
+#pragma unroll
+                for (int hbl = 0; hbl < HBS; ++hbl) {
+                    const int hb = st * HBS + hbl;
+                    const h8 ah = *reinterpret_cast<const h8*>(sp + (2 * hbl) * 1024);
+                    const h8 al = *reinterpret_cast<const h8*>(sp + (2 * hbl + 1) * 1024);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[hb], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[hb], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[hb], acc, 0, 0, 0);
+                }
+                wcur += STAGE;
+                const int t = so0; so0 = so1; so1 = so2; so2 = t;
+            }
+            // acc[r] = dZ[(i = iblk*32 + frag_row(r, hh), j)][n] * sW * sD
+            const float x0j = x0s[j * 32 + c];
+            float sj = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dxa[r] = fmaf(acc[r], x0j, dxa[r]);
+                sj = fmaf(acc[r], xpr[r], sj);
+            }
+            sj += __shfl_xor(sj, 32);
+            if (hh == 0) dx0s[j * 32 + c] += sj * inv;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = iblk * 32 + frag_row(r, hh);
+            if (i < Hp && nok) dxp[(long)i * N + n] += dxa[r] * inv;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int idx = lane; idx < m * 32; idx += 64) {
+        const long nn = n0 + (idx & 31);
+        if (nn < N) dx0[(long)(idx >> 5) * N + nn] += dx0s[idx];
+    }
+}
+
+size_t x3_bwx_pack_elems(int H, int Hp, int m) {
+    const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
+    return (size_t)X3_HDR + ((size_t)g.NT * g.HBT + 2 * g.HBS) * 512;
+}
+
+int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
+    const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
+    hipError_t e = hipMemsetAsync(pack, 0, X3_HDR * sizeof(float), st);
+    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_bwd_pack memset: %s", hipGetErrorString(e));
+    const long nW = (long)H * Hp * m;
+    hipLaunchKernelGGL(x3_absmax_kernel, dim3(ceil_div(nW, 256 * 8) > 1024 ? 1024 : ceil_div(nW, 256 * 8)), dim3(256), 0,
+                       st, W, nW, reinterpret_cast<unsigned*>(pack));
+    const long total = ((long)g.NT * g.HBT + 2 * g.HBS) * 64;
+    hipLaunchKernelGGL(x3_bwx_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, W, H, Hp, m, g, total, pack);
+    return xdfm_check_launch("cin_bwd_pack (f16x3)");
+}
+
+template <int HBT>
+static int launch_bwx3(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m,
+                       long N, const X3BwxGeom& g, float* dxp, float* dx0, hipStream_t st) {
+    constexpr int HBS = HBT > 8 ? 8 : HBT;
+    const size_t lds = (size_t)3 * HBS * 2048 + (size_t)8 * m * 32 * sizeof(float);
+    if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds);
+    hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, pack, H, Hp, m,
+                       N, g.IB, dxp, dx0);
+    return xdfm_check_launch("cin_level_bwd_x (f16x3)");
+}
+
+int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
+                   float* dxp, float* dx0, hipStream_t st) {
+    const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
+    if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: packed weights must be 16-byte aligned");
+    switch (g.HBT) {
+        case 2: return launch_bwx3<2>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, st);
+        case 4: return launch_bwx3<4>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, st);
+        case 8: return launch_bwx3<8>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, st);
+        default: return launch_bwx3<16>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, st);
+    }
+}

@@ -75,3 +75,13 @@ size_t x3_fwd_pack_elems(int H, int Hp, int m);
 int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
 int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
                  int act, float* out, hipStream_t st);
+struct X3BwxGeom {
+    int HBT, HBS, IB;     // h-blocks (of 16) in total / per ring stage, i-blocks (of 32)
+    long NT;              // tiles = IB * m
+};
+X3BwxGeom x3_bwx_geom(int H, int Hp, int m);
+bool x3_bwx_usable(int H, int Hp, int m);
+size_t x3_bwx_pack_elems(int H, int Hp, int m);
+int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
+int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
+                   float* dxp, float* dx0, hipStream_t st);
