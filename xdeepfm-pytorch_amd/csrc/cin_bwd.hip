@@ -204,7 +204,6 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
 // =============================================================================================
 // dW kernel
 // =============================================================================================
-#define BWW_NC 32
 #define BWW_PITCH 33
 // wave tile: 32*MT rows of h  x  (32 i's of block iblk) x JT values of j, accumulated over the
 // block's n range; result added (fp32 atomics, 128-B row segments) into
@@ -668,13 +667,6 @@ __global__ void cin_bwd_w_unpack_kernel(const float* __restrict__ dWt, int H, in
 // =============================================================================================
 // host side
 // =============================================================================================
-static inline int bww_mt(int H) {
-    const int o = xdfm_opt(OPT_BWW_MT);
-    if (o == 1 || o == 2 || o == 4) return o;
-    return H > 64 ? 4 : (H > 32 ? 2 : 1);
-}
-#define BWW_JT 2
-
 template <int HS4>
 static int launch_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
                         int m, long N, float* dxp, float* dx0, hipStream_t st) {
@@ -691,33 +683,6 @@ static int launch_bwd_x(const float* dOut, const float* xp, const float* x0, con
         hipLaunchKernelGGL((cin_bwd_x_kernel<HS4, 1>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, Wz, H,
                            Hp, m, N, IB, dxp, dx0);
     return xdfm_check_launch("cin_level_bwd_x");
-}
-
-struct BwwGeom {
-    int MT, IB, JP, TPH, HG, Hpad, IPAD, gx, nsplit;
-    long n_per_split, slab;        // slab = elements of one dWt copy
-};
-static BwwGeom bww_geometry(int H, int Hp, int m, long N) {
-    BwwGeom g;
-    g.MT = bww_mt(H);
-    g.IB = ceil_div(Hp, 32);
-    g.JP = ceil_div(m, BWW_JT);
-    g.TPH = (int)round_up((long)g.JP * g.IB, 4);
-    g.HG = ceil_div(H, 32 * g.MT);
-    g.Hpad = g.HG * 32 * g.MT;
-    g.IPAD = g.IB * 32;
-    g.gx = g.HG * g.TPH / 4;
-    int nsplit = xdfm_opt(OPT_BWW_NSPLIT);
-    const int max_split = ceil_div(N, BWW_NC);
-    // default: one resident round -- 2 workgroups per CU (LDS / VGPR limit) x 256 CUs.  More splits
-    // only add reduction traffic and a ragged last round (1027 workgroups on 512 slots ran 3 rounds).
-    if (nsplit <= 0) nsplit = 512 / g.gx > 0 ? 512 / g.gx : 1;
-    if (nsplit > max_split) nsplit = max_split;
-    if (nsplit > 65535) nsplit = 65535;
-    g.n_per_split = round_up(ceil_div(N, nsplit), BWW_NC);
-    g.nsplit = ceil_div(N, g.n_per_split);
-    g.slab = (long)m * g.Hpad * g.IPAD;
-    return g;
 }
 
 template <int MT>
@@ -815,7 +780,12 @@ int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, co
 size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m, long N) {
     if (H <= 0 || Hp <= 0 || m <= 0 || N <= 0) return 0;
     const BwwGeom g = bww_geometry(H, Hp, m, N);
-    return (size_t)g.slab * (size_t)(xdfm_opt(OPT_BWW_SLAB) ? g.nsplit : 1);
+    const size_t f32 = (size_t)g.slab * (size_t)(xdfm_opt(OPT_BWW_SLAB) ? g.nsplit : 1);
+    if (xdfm_opt(OPT_CIN_MATH) == 1) {      // whether the f16x3 kernel runs also depends on pointer alignment
+        const size_t x3 = x3_bww_ws_elems(H, Hp, m, N);
+        return x3 > f32 ? x3 : f32;
+    }
+    return f32;
 }
 
 int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,
@@ -823,6 +793,7 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, in
     XDFM_REQUIRE(dOut && xp && x0 && ws && dW, "cin_level_bwd_w: null pointer");
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_w: bad shape H=%d Hp=%d m=%d", H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
+    if (x3_bww_usable(dOut, xp, x0, H, N)) return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
     switch (bww_mt(H)) {
         case 1: return launch_bwd_w<1>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
         case 2: return launch_bwd_w<2>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);

@@ -1,0 +1,312 @@
+// dW (K4b) in f16x3 arithmetic (see cin_x3.hip for the arithmetic).
+//   dW[h][(i,j)] = sum_n dOut[h][n] * xp[i][n] * x0[j][n]          autograd of deepctr/layers/interaction.py:218-229
+// The contraction runs over n, so the range-fitting scales are per ROW: dOut rows h, x_prev rows i, x0
+// rows j (row maxima by one reduction pass).  dOut is split once into fp16 hi / lo planes (it is the A
+// operand of every one of the K/32 column tiles); Z = xp*x0 is formed, scaled and split in registers.
+//
+//   pass 1  x3_rowmax_kernel      row maxima of dOut, x_prev, x0                 -> workspace header
+//   pass 2  x3_split_dout_kernel  dOut * sD[h] -> planes [Hpad][NP/32][hi 32 | lo 32] fp16 (zero padded)
+//   pass 3  cin_bwd_w_x3_kernel   MFMA; per n-split slabs (same tiling as the fp32 kernel)
+//   pass 4  x3_bww_unpack_kernel  ordered sum of the slabs, scales removed, [h][i*m+j] layout
+#include "xdfm_internal.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+__device__ __forceinline__ float x3w_pow2_scale(float amax, int target) {
+    const int E = (int)((__float_as_uint(amax) >> 23) & 0xff);
+    int be = 253 + target - E;
+    be = be < 1 ? 1 : (be > 253 ? 253 : be);
+    return E == 0 ? 1.f : __uint_as_float((unsigned)be << 23);
+}
+
+bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, long N) {
+    return xdfm_opt(OPT_CIN_MATH) == 1 && bww_mt(H) == 4 && N % 4 == 0 && N >= 32 &&
+           ((((size_t)dOut) | ((size_t)xp) | ((size_t)x0)) & 15) == 0;
+}
+
+struct X3BwwWs { long hdr, planes, NP; };     // element (float) counts of the workspace parts
+static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int m, long N) {
+    X3BwwWs w;
+    w.NP = round_up(N, 32);
+    w.hdr = round_up((long)g.Hpad + g.IPAD + m, 64);
+    w.planes = (long)g.Hpad * w.NP;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows [0, H) of dOut, [H, H+Hp) of xp, [H+Hp, H+Hp+m) of x0 -> hdr[0..Hpad), hdr[Hpad..Hpad+IPAD), hdr[Hpad+IPAD..)
+__global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict__ dOut, const float* __restrict__ xp,
+                                                       const float* __restrict__ x0, int H, int Hp, int m, long N,
+                                                       int Hpad, int IPAD, unsigned* __restrict__ hdr) {
+    const int row = blockIdx.y;
+    const float* src;
+    unsigned* dst;
+    if (row < H) { src = dOut + (long)row * N; dst = hdr + row; }
+    else if (row < H + Hp) { src = xp + (long)(row - H) * N; dst = hdr + Hpad + (row - H); }
+    else { src = x0 + (long)(row - H - Hp) * N; dst = hdr + Hpad + IPAD + (row - H - Hp); }
+    float v = 0.f;
+    const long base = (long)blockIdx.x * 4096;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long n = base + ((long)k * 256 + threadIdx.x) * 4;
+        if (n < N) {                                    // N % 4 == 0
+            const float4 a = *reinterpret_cast<const float4*>(src + n);
+            v = fmaxf(fmaxf(v, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(dst, __float_as_uint(v));
+}
+
+// one thread = 8 columns of one row: 128-B blocks [hi 32 halves | lo 32 halves] per 32 columns
+__global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restrict__ dOut, int H, long N, long NP,
+                                                           const unsigned* __restrict__ hdr, char* __restrict__ planes) {
+    const int row = blockIdx.y;
+    const long n = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (n >= NP) return;
+    float v[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) v[t] = 0.f;
+    if (row < H) {
+        const float s = x3w_pow2_scale(__uint_as_float(hdr[row]), 15);
+        const float* src = dOut + (long)row * N + n;
+        if (n < N) { const float4 a = *reinterpret_cast<const float4*>(src); v[0] = a.x * s; v[1] = a.y * s; v[2] = a.z * s; v[3] = a.w * s; }
+        if (n + 4 < N) { const float4 a = *reinterpret_cast<const float4*>(src + 4); v[4] = a.x * s; v[5] = a.y * s; v[6] = a.z * s; v[7] = a.w * s; }
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const _Float16 a = (_Float16)v[t];
+        hi[t] = a;
+        lo[t] = (_Float16)(v[t] - (float)a);
+    }
+    char* blk = planes + ((long)row * NP + (n & ~31L)) * 4 + (n & 31) * 2;     // 4 bytes per column and row
+    *reinterpret_cast<h8*>(blk) = hi;
+    *reinterpret_cast<h8*>(blk + 64) = lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS image of every staged row: 128 bytes = 8 chunks of 16 B, chunk q of row r at position q ^ ((r >> 1) & 7)
+// (r = row index inside its region).  A 16-byte fragment read by lanes r = 0..15 of the same logical
+// chunk then covers all 64 banks; the LDS-DMA writes lane-linear, so the XOR goes on the source address.
+__device__ __forceinline__ void x3w_dma16(const void* g, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void x3w_split2(float z0, float z1, h2& hi, h2& lo) {
+    const f2 z = {z0, z1};
+    hi = __builtin_convertvector(z, h2);
+    const f2 r = {z0 - (float)hi.x, z1 - (float)hi.y};
+    lo = __builtin_convertvector(r, h2);
+}
+
+// wave tile as in cin_bwd_w_dma4_kernel: 32*MT rows of h x (32 i's of block iblk) x JT = 2 values of j
+template <int MT>
+__global__ __launch_bounds__(256, 2) void cin_bwd_w_x3_kernel(
+    const char* __restrict__ planes, long PB, const float* __restrict__ xp, const float* __restrict__ x0,
+    const unsigned* __restrict__ hdr, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
+    int IPAD, float* __restrict__ dWt, long slab_stride) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int JT = 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int wt0 = blockIdx.x * 4;
+    const int hg = wt0 / TPH;
+    const int tin = wt0 + wave - hg * TPH;
+    const bool active = tin < JP * IB;
+    const int jp = active ? tin / IB : 0;
+    const int iblk = active ? tin - jp * IB : 0;
+    const long NP = PB >> 2;
+    const long n_begin = (long)blockIdx.y * n_per_split;
+    const long n_end = (n_begin + n_per_split < NP) ? n_begin + n_per_split : NP;   // multiples of 32
+    const int nch = (int)((n_end - n_begin) / BWW_NC);
+
+    constexpr int DROWS = 32 * MT;
+    constexpr int WROWS = 32 + 8;                       // x_prev block + one 8-row group holding the x0 rows
+    constexpr int BUF = (DROWS + 4 * WROWS) * 128;      // bytes
+    constexpr int ND_D = DROWS / 32;
+    constexpr int NDMA = ND_D + 4 + 1;
+
+    const int lrow = lane >> 3, pc = lane & 7;
+    const int drow0 = wave * (DROWS / 4);
+    auto swz = [](int row) { return (row >> 1) & 7; };
+
+    auto dma_k = [&](int k, long nc0, int buf) {
+        char* base = smem + buf * BUF;
+        if (k < ND_D) {
+            const int row = drow0 + 8 * k + lrow;
+            const int q = pc ^ swz(row);
+            x3w_dma16(planes + (long)(hg * DROWS + row) * PB + nc0 * 4 + q * 16, base + (drow0 + 8 * k) * 128);
+        } else if (k < ND_D + 4) {
+            const int kk = k - ND_D;
+            char* wb = base + (DROWS + wave * WROWS) * 128;
+            const int row = 8 * kk + lrow;
+            int i = iblk * 32 + row;
+            i = i < Hp ? i : Hp - 1;
+            long col = nc0 + (pc ^ swz(row)) * 4;
+            col = col < N - 4 ? col : N - 4;            // columns >= N meet zero rows of the dOut planes
+            x3w_dma16(xp + (long)i * N + col, wb + (8 * kk) * 128);
+        } else {
+            char* wb = base + (DROWS + wave * WROWS + 32) * 128;
+            int j = jp * JT + (lrow < JT ? lrow : JT - 1);     // rows >= JT of the group are never read
+            j = j < m ? j : m - 1;
+            long col = nc0 + pc * 4;                    // rows 0, 1 of the group: swizzle 0
+            col = col < N - 4 ? col : N - 4;
+            x3w_dma16(x0 + (long)j * N + col, wb);
+        }
+    };
+
+    // per-lane scale of the B operand: sxp[i] * sx0[j]
+    float fz[JT];
+    {
+        const int i = iblk * 32 + r;
+        const float sx = x3w_pow2_scale(__uint_as_float(hdr[Hpad + (i < IPAD ? i : 0)]), 7);
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j = jp * JT + jt;
+            fz[jt] = (i < Hp && j < m) ? sx * x3w_pow2_scale(__uint_as_float(hdr[Hpad + IPAD + (j < m ? j : 0)]), 7) : 0.f;
+        }
+    }
+
+    f32x16 acc[MT][JT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[mt][jt][q] = 0.f;
+
+    const int sr = swz(r);
+    auto compute = [&](int buf, long next_nc0, int next_buf) {
+        const char* dS = smem + buf * BUF;
+        const char* xS = dS + (DROWS + wave * WROWS) * 128;
+        const char* zS = xS + 32 * 128;
+        const bool has_next = next_nc0 >= 0;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            // B operand: Z[(i_r, j)][n = 16 nb + 8 hh + t], t < 8
+            const int q0 = nb * 4 + 2 * hh;
+            const float4 xa = *reinterpret_cast<const float4*>(xS + (r * 8 + (q0 ^ sr)) * 16);
+            const float4 xb = *reinterpret_cast<const float4*>(xS + (r * 8 + ((q0 + 1) ^ sr)) * 16);
+            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            h8 bh[JT], bl[JT];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const float4 za = *reinterpret_cast<const float4*>(zS + (jt * 8 + q0) * 16);
+                const float4 zb = *reinterpret_cast<const float4*>(zS + (jt * 8 + q0 + 1) * 16);
+                const float zv[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    h2 hi, lo;
+                    x3w_split2(xv[2 * t2] * fz[jt] * zv[2 * t2], xv[2 * t2 + 1] * fz[jt] * zv[2 * t2 + 1], hi, lo);
+                    bh[jt][2 * t2] = hi.x; bh[jt][2 * t2 + 1] = hi.y;
+                    bl[jt][2 * t2] = lo.x; bl[jt][2 * t2 + 1] = lo.y;
+                }
+            }
+            if (has_next) {
+#pragma unroll
+                for (int k = nb * ((NDMA + 1) / 2); k < (nb + 1) * ((NDMA + 1) / 2); ++k)
+                    if (k < NDMA) dma_k(k, next_nc0, next_buf);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int qa = nb * 2 + hh;
+                const h8 ah = *reinterpret_cast<const h8*>(dS + ((mt * 32 + r) * 8 + (qa ^ sr)) * 16);
+                const h8 al = *reinterpret_cast<const h8*>(dS + ((mt * 32 + r) * 8 + ((qa + 4) ^ sr)) * 16);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[jt], acc[mt][jt], 0, 0, 0);
+                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[jt], acc[mt][jt], 0, 0, 0);
+                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[jt], acc[mt][jt], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    if (nch > 0) {
+#pragma unroll
+        for (int k = 0; k < NDMA; ++k) dma_k(k, n_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+        const long nxt = (ch + 1 < nch) ? n_begin + (long)(ch + 1) * BWW_NC : -1;
+        compute(ch & 1, nxt, (ch + 1) & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    if (!active) return;
+    const int i = iblk * 32 + r;
+    float* __restrict__ dst = dWt + (long)blockIdx.y * slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j = jp * JT + jt;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int h = hg * 32 * MT + mt * 32 + frag_row(q, hh);
+                if (i < Hp && j < m) dst[((long)j * Hpad + h) * IPAD + i] = acc[mt][jt][q];
+            }
+        }
+}
+
+// dW[h][i*m+j] = (sum over n-splits of dWt[split][j][h][i]) / (sD[h] * sxp[i] * sx0[j])
+__global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const unsigned* __restrict__ hdr, int H, int Hp, int m,
+                                     int Hpad, int IPAD, int nslab, long slab_stride, float* __restrict__ dW) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)m * Hpad * IPAD;
+    if (idx >= total) return;
+    const int i = (int)(idx % IPAD);
+    const long jh = idx / IPAD;
+    const int h = (int)(jh % Hpad), j = (int)(jh / Hpad);
+    if (i >= Hp || h >= H) return;
+    float acc = 0.f;
+    for (int k = 0; k < nslab; ++k) acc += dWt[(long)k * slab_stride + idx];
+    const float sd = x3w_pow2_scale(__uint_as_float(hdr[h]), 15);
+    const float sx = x3w_pow2_scale(__uint_as_float(hdr[Hpad + i]), 7);
+    const float sz = x3w_pow2_scale(__uint_as_float(hdr[Hpad + IPAD + j]), 7);
+    dW[(long)h * ((long)Hp * m) + (long)i * m + j] = acc * (1.f / sd) * (1.f / sx) * (1.f / sz);
+}
+
+// ---------------------------------------------------------------------------------------------
+size_t x3_bww_ws_elems(int H, int Hp, int m, long N) {
+    const BwwGeom g = bww_geometry(H, Hp, m, N);
+    const X3BwwWs w = x3_bww_ws(g, m, N);
+    return (size_t)w.hdr + (size_t)w.planes + (size_t)g.slab * g.nsplit;
+}
+
+int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
+                   float* dW, hipStream_t st) {
+    BwwGeom g = bww_geometry(H, Hp, m, N);
+    const X3BwwWs w = x3_bww_ws(g, m, N);
+    if ((((size_t)ws) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_w: workspace must be 16-byte aligned");
+    unsigned* hdr = reinterpret_cast<unsigned*>(ws);
+    char* planes = reinterpret_cast<char*>(ws + w.hdr);
+    float* slabs = ws + w.hdr + w.planes;
+    hipError_t e = hipMemsetAsync(hdr, 0, (size_t)w.hdr * sizeof(float), st);
+    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_level_bwd_w memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(x3_rowmax_kernel, dim3(ceil_div(N, 4096), H + Hp + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, m, N,
+                       g.Hpad, g.IPAD, hdr);
+    hipLaunchKernelGGL(x3_split_dout_kernel, dim3(ceil_div(w.NP, 2048), g.Hpad), dim3(256), 0, st, dOut, H, N, w.NP, hdr,
+                       planes);
+    int rc = xdfm_check_launch("cin_level_bwd_w split");
+    if (rc) return rc;
+    const size_t lds = (size_t)2 * (32 * 4 + 4 * (32 + 8)) * 128;
+    hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4>), dim3(g.gx, g.nsplit), dim3(256), lds, st, planes, w.NP * 4, xp, x0, hdr, Hp,
+                       m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab);
+    rc = xdfm_check_launch("cin_level_bwd_w (f16x3)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(x3_bww_unpack_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, slabs, hdr, H, Hp, m, g.Hpad,
+                       g.IPAD, g.nsplit, g.slab, dW);
+    return xdfm_check_launch("cin_level_bwd_w unpack (f16x3)");
+}

@@ -85,3 +85,45 @@ size_t x3_bwx_pack_elems(int H, int Hp, int m);
 int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
 int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
                    float* dxp, float* dx0, hipStream_t st);
+
+// ---- dW geometry (cin_bwd.hip, cin_x3_bww.hip) ---------------------------------------------------
+#define BWW_NC 32         // columns per staged chunk
+static inline int bww_mt(int H) {
+    const int o = xdfm_opt(OPT_BWW_MT);
+    if (o == 1 || o == 2 || o == 4) return o;
+    return H > 64 ? 4 : (H > 32 ? 2 : 1);
+}
+#define BWW_JT 2
+
+struct BwwGeom {
+    int MT, IB, JP, TPH, HG, Hpad, IPAD, gx, nsplit;
+    long n_per_split, slab;        // slab = elements of one dWt copy
+};
+static inline BwwGeom bww_geometry(int H, int Hp, int m, long N) {
+    BwwGeom g;
+    g.MT = bww_mt(H);
+    g.IB = ceil_div(Hp, 32);
+    g.JP = ceil_div(m, BWW_JT);
+    g.TPH = (int)round_up((long)g.JP * g.IB, 4);
+    g.HG = ceil_div(H, 32 * g.MT);
+    g.Hpad = g.HG * 32 * g.MT;
+    g.IPAD = g.IB * 32;
+    g.gx = g.HG * g.TPH / 4;
+    int nsplit = xdfm_opt(OPT_BWW_NSPLIT);
+    const int max_split = ceil_div(N, BWW_NC);
+    // default: one resident round -- 2 workgroups per CU (LDS / VGPR limit) x 256 CUs.  More splits
+    // only add reduction traffic and a ragged last round (1027 workgroups on 512 slots ran 3 rounds).
+    if (nsplit <= 0) nsplit = 512 / g.gx > 0 ? 512 / g.gx : 1;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > 65535) nsplit = 65535;
+    g.n_per_split = round_up(ceil_div(N, nsplit), BWW_NC);
+    g.nsplit = ceil_div(N, g.n_per_split);
+    g.slab = (long)m * g.Hpad * g.IPAD;
+    return g;
+}
+
+
+bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, long N);
+size_t x3_bww_ws_elems(int H, int Hp, int m, long N);
+int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
+                   float* dW, hipStream_t st);
