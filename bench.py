@@ -29,6 +29,13 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+F16_MFMA_PEAK_TFLOPS = 2516.6      # dense f16/bf16 MFMA: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz (same guide, ~2.5 PF)
+# cin_math = 1 ("f16x3"): every fp32 product of the contraction is three f16 MFMAs (hi*hi + hi*lo + lo*hi,
+# fp32 accumulate), so the fp32-equivalent ceiling of that path is a third of the dense f16 peak.
+CIN_MATH = {0: ("f32mfma", FP32_MFMA_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32 on fp32 operands"),
+            1: ("f16x3", F16_MFMA_PEAK_TFLOPS / 3.0,
+                "fp32 operands split into fp16 hi+lo, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; "
+                "peak = dense f16 MFMA peak / 3")}
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -146,6 +153,7 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=1024)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other CIN arithmetic")
     ap.add_argument("--option", action="append", default=[], help="libxdfm tuning knob key=value")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
                     "to rehearse the multi-rank path with several ranks on one GPU)")
@@ -196,28 +204,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log("warm-up")
-    for s in range(args.warmup):
-        train_step(model, *batches[s % n_res], dp)
-    barrier()
-    log("timed region")
-    ops.PROFILE = []                       # (name, flops, start_event, end_event) per heavy launch
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        loss = train_step(model, *batches[s % n_res], dp)
-    t_host = time.perf_counter() - t0
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed(steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks."""
+        for s in range(warmup):
+            train_step(model, *batches[s % n_res], dp)
+        barrier()
+        ops.PROFILE = []                   # (name, flops, start_event, end_event) per heavy launch
+        t0 = time.perf_counter()
+        for s in range(steps):
+            loss = train_step(model, *batches[s % n_res], dp)
+        t_host = time.perf_counter() - t0
+        barrier()
+        dt = time.perf_counter() - t0
+        prof, ops.PROFILE = ops.PROFILE, None
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if not np.isfinite(float(loss.item())):
+            raise RuntimeError("non-finite loss in the benchmark loop")
+        return dt, t_host, prof
+
+    math_mode = _lib.get_option("cin_math")
+    log("warm-up + timed region (cin_math=%s)" % CIN_MATH[math_mode][0])
+    dt, t_host, prof = timed(args.steps, args.warmup)
     log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (dt / args.steps * 1e3,
                                                                         t_host / args.steps * 1e3))
-    prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if not np.isfinite(float(loss.item())):
-        raise RuntimeError("non-finite loss in the benchmark loop")
+    alt = None
+    if world == 1 and not args.no_alt:
+        # the same K steps with the other arithmetic of the CIN contraction, for reference in the same line
+        other = 1 - math_mode
+        _lib.set_option("cin_math", other)
+        adt, _, _ = timed(args.steps, min(args.warmup, 3))
+        _lib.set_option("cin_math", math_mode)
+        alt = dict(cin_math=CIN_MATH[other][0], value=round(B * args.steps / adt, 1), unit="examples/sec",
+                   ms_per_step=round(adt / args.steps * 1e3, 4), arithmetic=CIN_MATH[other][2])
+        log("other arithmetic (%s): %.3f ms/step" % (CIN_MATH[other][0], adt / args.steps * 1e3))
 
     if rank == 0:
         per_kernel = {}
@@ -231,9 +254,11 @@ def main():
         if mfma:
             name, (secs, flops, n) = max(mfma.items(), key=lambda kv: kv[1][0])
             achieved = flops / secs / 1e12
-            roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=FP32_MFMA_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), traffic=None,
-                        launches=n, avg_ms=round(secs / n * 1e3, 4))
+            peak = CIN_MATH[math_mode][1]
+            roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1),
+                        unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
+                        launches=n, avg_ms=round(secs / n * 1e3, 4),
+                        note="fp32-equivalent FLOPs (2*H*Hp*m*N per launch); " + CIN_MATH[math_mode][2])
         kernels = {}
         for k, v in sorted(per_kernel.items()):
             rate = v[1] / v[0] if v[0] > 0 else 0.0
@@ -254,9 +279,12 @@ def main():
                                        args.workload, cfg["n_sparse"], cfg["n_dense"], cfg["emb_dim"],
                                        list(cfg["cin"]), list(cfg["dnn"]), args.vocab, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
+            "cin_math": CIN_MATH[math_mode][0],
             "roofline": roof,
             "kernels": kernels,
         }
+        if alt is not None:
+            out["other_arithmetic"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.vocab, args.cpu_rows, args.cpu_steps)
         print(json.dumps(out))

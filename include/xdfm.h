@@ -42,7 +42,15 @@ enum { XDFM_ACT_LINEAR = 0, XDFM_ACT_RELU = 1 };
 int xdfm_abi_version(void);
 const char* xdfm_last_error(void);          /* [host] thread-local, never NULL */
 int xdfm_device_count(void);                /* <0: HIP error code negated */
-/* tuning knobs for A/B runs (e.g. "fwd_nf", "bww_nsplit"); unknown key -> XDFM_ERR_INVALID */
+/* tuning knobs for A/B runs (e.g. "fwd_nf", "bww_nsplit"); unknown key -> XDFM_ERR_INVALID.
+ * "cin_math": arithmetic of the CIN contraction (K3 / K4).  Operands, accumulators and results are fp32
+ * in both modes; the packed-weight and workspace layouts (and the *_elems sizes) depend on the mode, so
+ * set it before the *_pack_elems / *_ws_elems calls of a step and keep it for that step.
+ *   1 (default) "f16x3": each fp32 operand is split into two fp16 halves (hi + lo, 22 mantissa bits, exact
+ *      power-of-two range fitting) and each product is three v_mfma_f32_32x32x16_f16 accumulated in fp32;
+ *      error against an fp64 evaluation <= that of mode 0 (tests/test_gpu_parity.py); shapes without an
+ *      f16x3 kernel (odd field counts in the forward, H <= 64 in dW, ...) run mode 0 kernels;
+ *   0 "f32mfma": v_mfma_f32_32x32x2_f32 on the fp32 operands. */
 int xdfm_set_option(const char* key, int value);
 int xdfm_get_option(const char* key);
 

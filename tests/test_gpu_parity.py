@@ -31,6 +31,17 @@ def gclose(got, want, msg=""):
     close(got, want, rtol=2e-4, atol=2e-5 * float(np.abs(want).max()) + 1e-9, msg=msg)
 
 
+@pytest.fixture(params=[0, 1], ids=["f32mfma", "f16x3"])
+def cin_math(request):
+    """Both arithmetic modes of the CIN contraction: v_mfma_f32_32x32x2_f32 on fp32 operands, and the
+    f16x3 split (fp32 = hi + lo fp16, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate)."""
+    from xdfm_amd import _lib
+    old = _lib.get_option("cin_math")
+    _lib.set_option("cin_math", request.param)
+    yield request.param
+    _lib.set_option("cin_math", old)
+
+
 # --------------------------------------------------------------------------------------------- #
 def test_native_library_is_loaded():
     from xdfm_amd import _lib
@@ -42,7 +53,7 @@ def test_native_library_is_loaded():
 
 
 @pytest.mark.parametrize("name", golden_names("cin_"))
-def test_cin_layer_vs_reference_golden(name):
+def test_cin_layer_vs_reference_golden(name, cin_math):
     from deepctr.layers import CIN
     dev = _dev()
     g = load_golden(name)
@@ -69,7 +80,7 @@ def test_cin_layer_vs_reference_golden(name):
                                        (1, 26, 16, (256, 128, 128)),             # one example (last batch of an epoch)
                                        (6, 22, 32, (512, 256, 256, 128)),        # BASELINE config-5 layer sizes (H > 256)
                                        (3, 3, 4, (300, 4))])
-def test_cin_vs_oracle_random(B, m, D, ls):
+def test_cin_vs_oracle_random(B, m, D, ls, cin_math):
     from deepctr.layers import CIN
     from oracle import xdeepfm_oracle as orc
     dev = _dev()
@@ -112,6 +123,80 @@ def _near_zero_preactivation_columns(x0, W, Bs, eps):
         cur = torch.relu(z)
         hidden = cur[:, : w.shape[0] // 2] if i != len(W) - 1 else None
     return risky
+
+
+def _cin_fp64(x, Ws, Bs):
+    """CIN forward in fp64 torch ops (deepctr/layers/interaction.py:207-248, split_half, relu)."""
+    B, m, D = x.shape
+    hidden, finals = x, []
+    for i, (w, b) in enumerate(zip(Ws, Bs)):
+        z = torch.einsum("bhd,bmd->bhmd", hidden, x).reshape(B, hidden.shape[1] * m, D)
+        cur = torch.relu(torch.nn.functional.conv1d(z, w, b))
+        if i != len(Ws) - 1:
+            hidden, direct = cur[:, : w.shape[0] // 2], cur[:, w.shape[0] // 2:]
+        else:
+            direct = cur
+        finals.append(direct)
+    return torch.cat(finals, 1).sum(-1)
+
+
+@pytest.mark.parametrize("B,m,D,ls,spread", [(512, 26, 16, (256, 128, 128), False), (512, 26, 16, (256, 128, 128), True),
+                                              (96, 22, 32, (512, 256, 256, 128), False), (300, 26, 8, (128, 128), True)])
+def test_cin_f16x3_is_as_accurate_as_fp32_mfma(B, m, D, ls, spread):
+    """The claim that makes f16x3 an fp32 path: against an fp64 evaluation of the same CIN its error is
+    not larger than that of the fp32-MFMA kernels (both are dominated by the fp32 accumulation).  With
+    `spread` the examples' magnitudes cover 8 decades (per-column range fitting of the fp16 halves)."""
+    from deepctr.layers import CIN
+    from xdfm_amd import _lib
+    dev = _dev()
+    torch.manual_seed(B + m)
+    layer = CIN(m, ls, "relu", True, 0.0, 1024, device="cpu").to(dev)
+    x = torch.randn(B, m, D, device=dev) * 0.5
+    if spread:
+        x = x * torch.pow(10.0, torch.rand(B, 1, 1, device=dev) * 8 - 6)
+    W64 = [c.weight.detach().double().requires_grad_(True) for c in layer.conv1ds]
+    B64 = [c.bias.detach().double().requires_grad_(True) for c in layer.conv1ds]
+    # A ReLU whose pre-activation is within rounding of zero may switch on in one arithmetic and not in the
+    # other, which changes gradients legitimately: drop the examples that hold such a pre-activation
+    # (|z| < 1e-5 x the largest |z| of the same example, level and d) before comparing anything.
+    with torch.no_grad():
+        hid, safe = x.double(), torch.ones(B, dtype=torch.bool, device=dev)
+        for i, (w, b) in enumerate(zip(W64, B64)):
+            z = torch.nn.functional.conv1d(torch.einsum("bhd,bmd->bhmd", hid, x.double()).reshape(B, -1, D), w, b)
+            safe &= ~(z.abs() < 1e-5 * z.abs().amax(dim=1, keepdim=True)).flatten(1).any(dim=1)
+            hid = torch.relu(z)[:, : w.shape[0] // 2]
+    assert float(safe.float().mean()) > 0.3
+    x = x[safe].contiguous()
+    x64 = x.double().requires_grad_(True)
+    want = _cin_fp64(x64, W64, B64)
+    gout = torch.randn(want.shape, device=dev)
+    (want * gout.double()).sum().backward()
+    den = want.detach().abs().amax(dim=1, keepdim=True).clamp_min(1e-300)
+    err = {}
+    old = _lib.get_option("cin_math")
+    try:
+        for mode in (0, 1):
+            _lib.set_option("cin_math", mode)
+            for c in layer.conv1ds:
+                c.weight.grad = c.bias.grad = None
+            xg = x.clone().requires_grad_(True)
+            out = layer(xg)
+            (out * gout).sum().backward()
+            e = ((out.detach().double() - want.detach()) / den)
+            # per example: a small-magnitude example must be as accurate as a large one
+            gx = ((xg.grad.double() - x64.grad).abs().flatten(1).amax(dim=1) /
+                  x64.grad.abs().flatten(1).amax(dim=1).clamp_min(1e-300)).max().item()
+            err[mode] = dict(fwd_rms=e.pow(2).mean().sqrt().item(), fwd_max=e.abs().max().item(), dx=gx,
+                             dw=[((c.weight.grad.double() - w.grad).abs().amax() / w.grad.abs().amax()).item()
+                                 for c, w in zip(layer.conv1ds, W64)])
+    finally:
+        _lib.set_option("cin_math", old)
+    assert err[1]["fwd_rms"] <= 1.25 * err[0]["fwd_rms"] + 1e-9, err
+    assert err[1]["fwd_max"] <= 2.0 * err[0]["fwd_max"] + 1e-8, err
+    assert err[1]["fwd_max"] < 5e-6 and err[1]["dx"] < 5e-6, err
+    assert err[1]["dx"] <= 2.0 * err[0]["dx"] + 2e-7, err
+    for a, b in zip(err[1]["dw"], err[0]["dw"]):
+        assert a <= 2.0 * b + 2e-7 and a < 5e-6, err
 
 
 def test_cin_rejects_bad_input_like_reference():
@@ -176,7 +261,7 @@ def _build_model(g, dev):
 
 
 @pytest.mark.parametrize("name", golden_names("model_"))
-def test_model_vs_reference_golden(name):
+def test_model_vs_reference_golden(name, cin_math):
     dev = _dev()
     g = load_golden(name)
     model = _build_model(g, dev)
@@ -225,7 +310,7 @@ def test_model_vs_reference_golden(name):
     assert abs(M.roc_auc_score(yn, pred) - M.roc_auc_score(yn, g["pred_after"])) < 1e-5
 
 
-def test_fit_history_vs_reference_golden():
+def test_fit_history_vs_reference_golden(cin_math):
     from deepctr.inputs import DenseFeat, SparseFeat
     from deepctr.models import xDeepFM
     dev = _dev()
@@ -308,7 +393,7 @@ def test_gather_flags_out_of_range_ids():
     assert not plan.check_ids(dev)
 
 
-def test_full_size_cin_rows_vs_oracle_subset():
+def test_full_size_cin_rows_vs_oracle_subset(cin_math):
     """BASELINE config 2 shape (B=4096, m=26, D=16, cin=(256,128,128)): examples are independent,
     so 48 rows of the full-size launch are compared with the oracle run on just those rows, and
     gradients are checked through linearity: dW of the full batch restricted to a gout that is

@@ -9,7 +9,7 @@ static int g_opts[OPT_COUNT] = {
     /* OPT_BWW_SLAB */ 1,
     /* OPT_BWW_MT */ 0,
     /* OPT_DBG */ 0,
-    /* OPT_CIN_MATH */ 0,
+    /* OPT_CIN_MATH */ 1,
 };
 static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math"};
 

@@ -64,12 +64,32 @@ __device__ __forceinline__ void x3_split2(float z0, float z1, h2& hi, h2& lo) {
 
 // ---------------------------------------------------------------------------------------------
 // |W| maximum -> header slot 2 (as uint bits; non-negative floats order like their bit patterns)
-__global__ void x3_absmax_kernel(const float* __restrict__ W, long total, unsigned* __restrict__ hdr) {
+__global__ __launch_bounds__(1024) void x3_absmax_kernel(const float* __restrict__ W, long total, unsigned* __restrict__ hdr) {
+    __shared__ float red[16];
     float v = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+    const long nv = total >> 2;                                  // float4 part (W is 16-byte aligned or nv4 == 0)
+    const bool vec = (((size_t)W) & 15) == 0;
+    if (vec) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+            const float4 a = reinterpret_cast<const float4*>(W)[i];
+            v = fmaxf(fmaxf(v, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+        }
+    }
+    for (long i = (vec ? nv * 4 : 0) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
         v = fmaxf(v, fabsf(W[i]));
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(hdr + 2, __float_as_uint(v));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        v = red[threadIdx.x];
+        for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+        if (threadIdx.x == 0) atomicMax(hdr + 2, __float_as_uint(v));    // one atomic per block
+    }
+}
+
+static void x3_launch_absmax(const float* W, long total, float* pack, hipStream_t st) {
+    const int blocks = ceil_div(total, 1024 * 16) > 64 ? 64 : ceil_div(total, 1024 * 16);
+    hipLaunchKernelGGL(x3_absmax_kernel, dim3(blocks), dim3(1024), 0, st, W, total, reinterpret_cast<unsigned*>(pack));
 }
 
 // pack layout (after the X3_HDR-float header: [0] = sW, [1] = 1/sW, [2] = max|W| bits):
@@ -276,8 +296,7 @@ int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
     hipError_t e = hipMemsetAsync(pack, 0, X3_HDR * sizeof(float), st);
     if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_fwd_pack memset: %s", hipGetErrorString(e));
     const long total = (long)H * Hp * m;
-    hipLaunchKernelGGL(x3_absmax_kernel, dim3(ceil_div(total, 256 * 8) > 1024 ? 1024 : ceil_div(total, 256 * 8)), dim3(256),
-                       0, st, W, total, reinterpret_cast<unsigned*>(pack));
+    x3_launch_absmax(W, total, pack, st);
     const long threads = (long)g.MB * (g.NS + 2) * g.MT * 64;
     hipLaunchKernelGGL(x3_fwd_pack_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, st, W, H, Hp, m, g, pack);
     return xdfm_check_launch("cin_fwd_pack (f16x3)");
@@ -484,8 +503,7 @@ int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
     hipError_t e = hipMemsetAsync(pack, 0, X3_HDR * sizeof(float), st);
     if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_bwd_pack memset: %s", hipGetErrorString(e));
     const long nW = (long)H * Hp * m;
-    hipLaunchKernelGGL(x3_absmax_kernel, dim3(ceil_div(nW, 256 * 8) > 1024 ? 1024 : ceil_div(nW, 256 * 8)), dim3(256), 0,
-                       st, W, nW, reinterpret_cast<unsigned*>(pack));
+    x3_launch_absmax(W, nW, pack, st);
     const long total = ((long)g.NT * g.HBT + 2 * g.HBS) * 64;
     hipLaunchKernelGGL(x3_bwx_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, W, H, Hp, m, g, total, pack);
     return xdfm_check_launch("cin_bwd_pack (f16x3)");

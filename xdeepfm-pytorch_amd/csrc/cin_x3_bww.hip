@@ -41,6 +41,7 @@ static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int m, long N) {
 
 // ---------------------------------------------------------------------------------------------
 // rows [0, H) of dOut, [H, H+Hp) of xp, [H+Hp, H+Hp+m) of x0 -> hdr[0..Hpad), hdr[Hpad..Hpad+IPAD), hdr[Hpad+IPAD..)
+#define X3_RM_COLS 16384      // columns per block of the row-maximum pass
 __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict__ dOut, const float* __restrict__ xp,
                                                        const float* __restrict__ x0, int H, int Hp, int m, long N,
                                                        int Hpad, int IPAD, unsigned* __restrict__ hdr) {
@@ -51,9 +52,9 @@ __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict_
     else if (row < H + Hp) { src = xp + (long)(row - H) * N; dst = hdr + Hpad + (row - H); }
     else { src = x0 + (long)(row - H - Hp) * N; dst = hdr + Hpad + IPAD + (row - H - Hp); }
     float v = 0.f;
-    const long base = (long)blockIdx.x * 4096;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    const long base = (long)blockIdx.x * X3_RM_COLS;
+#pragma unroll 4
+    for (int k = 0; k < X3_RM_COLS / 1024; ++k) {
         const long n = base + ((long)k * 256 + threadIdx.x) * 4;
         if (n < N) {                                    // N % 4 == 0
             const float4 a = *reinterpret_cast<const float4*>(src + n);
@@ -61,7 +62,13 @@ __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict_
         }
     }
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0 && v > 0.f) atomicMax(dst, __float_as_uint(v));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (v > 0.f) atomicMax(dst, __float_as_uint(v));           // one atomic per block
+    }
 }
 
 // one thread = 8 columns of one row: 128-B blocks [hi 32 halves | lo 32 halves] per 32 columns
@@ -295,7 +302,7 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     float* slabs = ws + w.hdr + w.planes;
     hipError_t e = hipMemsetAsync(hdr, 0, (size_t)w.hdr * sizeof(float), st);
     if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_level_bwd_w memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(x3_rowmax_kernel, dim3(ceil_div(N, 4096), H + Hp + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, m, N,
+    hipLaunchKernelGGL(x3_rowmax_kernel, dim3(ceil_div(N, X3_RM_COLS), H + Hp + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, m, N,
                        g.Hpad, g.IPAD, hdr);
     hipLaunchKernelGGL(x3_split_dout_kernel, dim3(ceil_div(w.NP, 2048), g.Hpad), dim3(256), 0, st, dOut, H, N, w.NP, hdr,
                        planes);
