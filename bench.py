@@ -11,9 +11,13 @@ backward -> Adam step.  Inputs are in HBM before the timed region starts.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant hand-written kernel (by summed
-device time inside the timed region, HIP events on the launch stream); `cpu_baseline` is the CPU
-oracle (a port of the reference's op sequence) timed on this host's cores on a bounded sample.
+Rank 0 prints ONE JSON line.  The timed K steps run the way `fit` runs them: replayed from the HIP graph
+the model captured on its third step (single process; eager launches when row-parallel).  `roofline`
+describes the dominant hand-written kernel by summed device time, measured live right after the timed
+region over up to 10 of the same steps issued eagerly with HIP events around every launch on the launch
+stream (events cannot be recorded inside a graph replay; `profiles/` holds the rocprofv3 summary of the
+same command); `other_arithmetic` repeats the K steps with the other CIN arithmetic; `cpu_baseline` is
+the CPU oracle (a port of the reference's op sequence) timed on this host's cores on a bounded sample.
 """
 import argparse
 import json
@@ -204,12 +208,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(steps, warmup):
-        """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks."""
+    def timed(steps, warmup, kernel_events=False):
+        """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks.
+        kernel_events: bracket every heavy launch with HIP events on the launch stream (ops.PROFILE); the
+        step then runs from eager launches (events cannot be recorded inside a replayed HIP graph)."""
         for s in range(warmup):
             train_step(model, *batches[s % n_res], dp)
         barrier()
-        ops.PROFILE = []                   # (name, flops, start_event, end_event) per heavy launch
+        ops.PROFILE = [] if kernel_events else None     # (name, flops, start_event, end_event) per heavy launch
         t0 = time.perf_counter()
         for s in range(steps):
             loss = train_step(model, *batches[s % n_res], dp)
@@ -227,16 +233,25 @@ def main():
         return dt, t_host, prof
 
     math_mode = _lib.get_option("cin_math")
+    # untimed: the first steps of a batch shape run eagerly and the third one captures the HIP graph the
+    # later steps are replayed from (xdfm_amd/graphstep.py); keep that out of the W + K steps
+    for s in range(4):
+        train_step(model, *batches[s % n_res], dp)
+    gstep = model.__dict__.get("_graphed_step")
     log("warm-up + timed region (cin_math=%s)" % CIN_MATH[math_mode][0])
-    dt, t_host, prof = timed(args.steps, args.warmup)
-    log("timed region done: %.3f ms/step (host enqueue %.3f ms/step)" % (dt / args.steps * 1e3,
-                                                                        t_host / args.steps * 1e3))
+    dt, t_host, _ = timed(args.steps, args.warmup)
+    replayed = gstep is not None and gstep.replays > 0
+    log("timed region done: %.3f ms/step (host enqueue %.3f ms/step, %s)" % (
+        dt / args.steps * 1e3, t_host / args.steps * 1e3,
+        "HIP graph replay, %d nodes" % max(e.nodes for e in gstep.entries.values()) if replayed else "eager launches"))
+    # per-kernel device times for the roofline: the same steps from eager launches, HIP events around each launch
+    _, _, prof = timed(min(args.steps, 10), 1, kernel_events=True)
     alt = None
     if world == 1 and not args.no_alt:
         # the same K steps with the other arithmetic of the CIN contraction, for reference in the same line
         other = 1 - math_mode
         _lib.set_option("cin_math", other)
-        adt, _, _ = timed(args.steps, min(args.warmup, 3))
+        adt, _, _ = timed(args.steps, 4)
         _lib.set_option("cin_math", math_mode)
         alt = dict(cin_math=CIN_MATH[other][0], value=round(B * args.steps / adt, 1), unit="examples/sec",
                    ms_per_step=round(adt / args.steps * 1e3, 4), arithmetic=CIN_MATH[other][2])
@@ -260,10 +275,12 @@ def main():
                         launches=n, avg_ms=round(secs / n * 1e3, 4),
                         note="fp32-equivalent FLOPs (2*H*Hp*m*N per launch); " + CIN_MATH[math_mode][2])
         kernels = {}
+        prof_steps = min(args.steps, 10)
+        calls_per_step = {k: v[2] / prof_steps for k, v in per_kernel.items()}
         for k, v in sorted(per_kernel.items()):
             rate = v[1] / v[0] if v[0] > 0 else 0.0
             kernels[k.replace("[bytes]", "")] = dict(
-                ms_per_step=round(v[0] / args.steps * 1e3, 4),
+                ms_per_step=round(v[0] / max(v[2], 1) * calls_per_step[k] * 1e3, 4),
                 **({"GBps": round(rate / 1e9, 1), "frac_hbm": round(rate / 1e9 / HBM_PEAK_GBS, 4)}
                    if k.endswith("[bytes]") else {"TFLOPs": round(rate / 1e12, 2)}))
         out = {
@@ -280,6 +297,7 @@ def main():
                                        list(cfg["cin"]), list(cfg["dnn"]), args.vocab, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
             "cin_math": CIN_MATH[math_mode][0],
+            "launch": "hip_graph_replay" if replayed else "eager",
             "roofline": roof,
             "kernels": kernels,
         }

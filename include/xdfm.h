@@ -53,6 +53,11 @@ int xdfm_device_count(void);                /* <0: HIP error code negated */
  *   0 "f32mfma": v_mfma_f32_32x32x2_f32 on the fp32 operands. */
 int xdfm_set_option(const char* key, int value);
 int xdfm_get_option(const char* key);
+/* [host] node types of a captured hipGraph_t (the host side replays the train step from a HIP graph):
+ * memset nodes are counted separately because they are not ordered reliably against neighbouring kernel
+ * nodes on ROCm 7.2 / gfx950 (tools/graph_memset_probe.py) -- a graph with n_memset > 0 must not be replayed;
+ * n_unexpected counts nodes that are neither kernel, memcpy, empty nor event nodes. */
+int xdfm_graph_node_census(void* graph, int* n_nodes, int* n_memset, int* n_unexpected);
 
 /* ------------------------------------------------------------------ embedding gather (K1)
  * replaces: deepctr/models/basemodel.py:368-370 (26x slice -> .long() -> nn.Embedding),
@@ -176,6 +181,13 @@ int xdfm_l2_reg_fwd(const float* const* ptrs, const long* numel, const float* co
                     float* partials, float* out, void* stream);
 int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* coeff, int T,
                     const float* gscale, float* gflat, const long* goff, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ dense-layer bias gradient
+ * replaces: autograd of deepctr/layers/core.py:120-134 w.r.t. the bias, grad_bias[c] = sum_r g[r][c].
+ * Atomics-free and without any memset (safe inside a captured HIP graph), fixed summation order.
+ * g [rows][ld] fp32 (ld >= cols); ws: xdfm_colsum_ws_elems(cols) floats; out [cols]. */
+size_t xdfm_colsum_ws_elems(int cols);
+int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* out, void* stream);
 
 #ifdef __cplusplus
 }

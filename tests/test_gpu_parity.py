@@ -553,3 +553,47 @@ def test_full_size_logloss_auc_vs_cpu_path():
     assert abs(M.log_loss(y, pred) - M.log_loss(y, want)) < 1e-5
     assert abs(M.roc_auc_score(y, pred) - M.roc_auc_score(y, want)) < 1e-5
     np.testing.assert_allclose(pred, want, rtol=1e-4, atol=2e-6)
+
+
+def test_graph_replay_of_train_step_matches_eager_launches():
+    """xdfm_amd/graphstep.py: from the third step on the train step is replayed from a captured HIP graph.
+    Same seed, same batches: the replayed run must follow the eager run (difference = fp32 atomics order of
+    the embedding scatter only), the captured graph must hold no memset node, and a change of what is baked
+    into the graph (here the learning rate) must re-capture instead of replaying stale launches."""
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from oracle import xdeepfm_oracle as orc
+    from xdfm_amd import graphstep
+    dev = _dev()
+    vocab, nd, D = [50, 31, 77, 12, 9, 40], 3, 8
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(nd)]
+
+    def run(use_graph):
+        model = xDeepFM(cols, cols, dnn_hidden_units=(32, 16), cin_layer_size=(16, 8), l2_reg_dnn=1e-5, device=dev)
+        model.compile("adam", "binary_crossentropy", metrics=[])
+        model.train()
+        step = graphstep.GraphedStep(model)
+        step.disabled = not use_graph
+        model.__dict__["_graphed_step"] = step
+        losses = []
+        for s in range(14):
+            if s == 9:
+                for pg in model.optim.param_groups:
+                    pg["lr"] = 3e-3
+            X, y = orc.synthetic_batch(256 if s != 6 else 100, vocab, nd, seed=100 + s)     # one ragged batch
+            out = model.train_on_batch(T(X).to(dev), T(y).to(dev))
+            losses.append(float(out[2].detach().reshape(-1)[0]))
+        return model, step, losses
+
+    m_g, step_g, l_g = run(True)
+    m_e, step_e, l_e = run(False)
+    assert step_e.replays == 0 and step_g.replays >= 6, (step_g.replays, step_g.disabled)
+    assert not step_g.disabled
+    graphs = [e for e in step_g.entries.values() if e.graph is not None]
+    assert len(graphs) == 2                                   # lr 1e-3 and lr 3e-3, batch 256
+    for e in graphs:
+        n, n_memset, n_other = graphstep.census(e.graph)
+        assert n > 50 and n_memset == 0 and n_other == 0
+    np.testing.assert_allclose(l_g, l_e, rtol=2e-5)
+    for (k, a), (_, b) in zip(m_g.state_dict().items(), m_e.state_dict().items()):
+        close(a, b.cpu().numpy(), rtol=2e-3, atol=2e-6, msg=k)

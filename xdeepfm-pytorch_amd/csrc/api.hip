@@ -1,4 +1,5 @@
 // Error text, tuning options and small host-side entry points of libxdfm_hip.
+#include <stdlib.h>
 #include <string.h>
 #include "xdfm_internal.h"
 
@@ -33,6 +34,29 @@ int xdfm_device_count(void) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     return e == hipSuccess ? n : -(int)e;
+}
+
+int xdfm_graph_node_census(void* graph, int* n_nodes, int* n_memset, int* n_unexpected) {
+    if (!graph || !n_nodes || !n_memset || !n_unexpected) return xdfm_fail(XDFM_ERR_INVALID, "graph_node_census: null pointer");
+    size_t n = 0;
+    hipError_t e = hipGraphGetNodes((hipGraph_t)graph, nullptr, &n);
+    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "hipGraphGetNodes: %s", hipGetErrorString(e));
+    hipGraphNode_t* nodes = (hipGraphNode_t*)malloc((n ? n : 1) * sizeof(hipGraphNode_t));
+    if (!nodes) return xdfm_fail(XDFM_ERR_LAUNCH, "graph_node_census: out of host memory");
+    e = hipGraphGetNodes((hipGraph_t)graph, nodes, &n);
+    int ms = 0, other = 0;
+    for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+        hipGraphNodeType t;
+        e = hipGraphNodeGetType(nodes[i], &t);
+        if (e != hipSuccess) break;
+        if (t == hipGraphNodeTypeMemset) ++ms;
+        else if (t != hipGraphNodeTypeKernel && t != hipGraphNodeTypeMemcpy && t != hipGraphNodeTypeEmpty &&
+                 t != hipGraphNodeTypeWaitEvent && t != hipGraphNodeTypeEventRecord) ++other;
+    }
+    free(nodes);
+    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "graph_node_census: %s", hipGetErrorString(e));
+    *n_nodes = (int)n; *n_memset = ms; *n_unexpected = other;
+    return XDFM_OK;
 }
 
 int xdfm_set_option(const char* key, int value) {

@@ -63,11 +63,15 @@ __device__ __forceinline__ void x3_split2(float z0, float z1, h2& hi, h2& lo) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// |W| maximum -> header slot 2 (as uint bits; non-negative floats order like their bit patterns)
-__global__ __launch_bounds__(1024) void x3_absmax_kernel(const float* __restrict__ W, long total, unsigned* __restrict__ hdr) {
+// |W| maximum: every block stores its partial maximum in header slot X3_HDR_PART + blockIdx.x (plain stores,
+// no zero-initialised cell and no atomics: nothing here depends on a memset node inside a captured graph);
+// the pack kernels reduce the <= X3_ABSMAX_BLOCKS partials themselves.
+#define X3_ABSMAX_BLOCKS 64
+#define X3_HDR_PART 64
+__global__ __launch_bounds__(1024) void x3_absmax_kernel(const float* __restrict__ W, long total, float* __restrict__ hdr) {
     __shared__ float red[16];
     float v = 0.f;
-    const long nv = total >> 2;                                  // float4 part (W is 16-byte aligned or nv4 == 0)
+    const long nv = total >> 2;
     const bool vec = (((size_t)W) & 15) == 0;
     if (vec) {
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
@@ -83,25 +87,35 @@ __global__ __launch_bounds__(1024) void x3_absmax_kernel(const float* __restrict
     if (threadIdx.x < 16) {
         v = red[threadIdx.x];
         for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-        if (threadIdx.x == 0) atomicMax(hdr + 2, __float_as_uint(v));    // one atomic per block
+        if (threadIdx.x == 0) hdr[X3_HDR_PART + blockIdx.x] = v;
     }
 }
 
-static void x3_launch_absmax(const float* W, long total, float* pack, hipStream_t st) {
-    const int blocks = ceil_div(total, 1024 * 16) > 64 ? 64 : ceil_div(total, 1024 * 16);
-    hipLaunchKernelGGL(x3_absmax_kernel, dim3(blocks), dim3(1024), 0, st, W, total, reinterpret_cast<unsigned*>(pack));
+static inline int x3_absmax_blocks(long total) {
+    const int b = ceil_div(total, 1024 * 16);
+    return b > X3_ABSMAX_BLOCKS ? X3_ABSMAX_BLOCKS : b;
 }
 
-// pack layout (after the X3_HDR-float header: [0] = sW, [1] = 1/sW, [2] = max|W| bits):
+static void x3_launch_absmax(const float* W, long total, float* pack, hipStream_t st) {
+    hipLaunchKernelGGL(x3_absmax_kernel, dim3(x3_absmax_blocks(total)), dim3(1024), 0, st, W, total, pack);
+}
+
+__device__ __forceinline__ float x3_weight_scale(const float* __restrict__ hdr, int nparts) {
+    float mx = 0.f;
+    for (int k = 0; k < nparts; ++k) mx = fmaxf(mx, hdr[X3_HDR_PART + k]);
+    return x3_pow2_scale(mx, 15);
+}
+
+// pack layout (after the X3_HDR-float header: [0] = sW, [1] = 1/sW, [64..127] = partial maxima of |W|):
 //   [mb][g < NS+2][mt < MT][p: 0 = hi, 1 = lo][lane][8 halves]   -- 1 KB per (mt, p) fragment
 // element t of lane (r = lane & 31, hh = lane >> 5) of step g = (blk, s):
 //   row = (mb*MT + mt)*32 + r,  q = 8s + t,  il = q / m,  j = q % m,  i = blk*8 + hh*RH + il
-__global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3Geom G,
+__global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3Geom G, int nparts,
                                    float* __restrict__ pack) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)G.MB * (G.NS + 2) * G.MT * 64;
     if (idx >= total) return;
-    const float sW = x3_pow2_scale(pack[2], 15);
+    const float sW = x3_weight_scale(pack, nparts);
     if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
     const int lane = (int)(idx & 63);
     long rest = idx >> 6;
@@ -293,12 +307,11 @@ size_t x3_fwd_pack_elems(int H, int Hp, int m) {
 
 int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
-    hipError_t e = hipMemsetAsync(pack, 0, X3_HDR * sizeof(float), st);
-    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_fwd_pack memset: %s", hipGetErrorString(e));
     const long total = (long)H * Hp * m;
     x3_launch_absmax(W, total, pack, st);
     const long threads = (long)g.MB * (g.NS + 2) * g.MT * 64;
-    hipLaunchKernelGGL(x3_fwd_pack_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, st, W, H, Hp, m, g, pack);
+    hipLaunchKernelGGL(x3_fwd_pack_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, st, W, H, Hp, m, g,
+                       x3_absmax_blocks(total), pack);
     return xdfm_check_launch("cin_fwd_pack (f16x3)");
 }
 
@@ -349,10 +362,10 @@ bool x3_bwx_usable(int H, int Hp, int m) {
 // pack: [tile = iblk*m + j][hb < HBT][p][lane][8 halves]; element t of lane (r, hh):
 //   W[h = 16*hb + 8*hh + t][(iblk*32 + r)*m + j] * sW   (0 outside); two dummy stages appended.
 __global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3BwxGeom G, long total,
-                                   float* __restrict__ pack) {
+                                   int nparts, float* __restrict__ pack) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
-    const float sW = x3_pow2_scale(pack[2], 15);
+    const float sW = x3_weight_scale(pack, nparts);
     if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
     const int lane = (int)(idx & 63);
     long rest = idx >> 6;
@@ -500,12 +513,11 @@ size_t x3_bwx_pack_elems(int H, int Hp, int m) {
 
 int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
-    hipError_t e = hipMemsetAsync(pack, 0, X3_HDR * sizeof(float), st);
-    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_bwd_pack memset: %s", hipGetErrorString(e));
     const long nW = (long)H * Hp * m;
     x3_launch_absmax(W, nW, pack, st);
     const long total = ((long)g.NT * g.HBT + 2 * g.HBS) * 64;
-    hipLaunchKernelGGL(x3_bwx_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, W, H, Hp, m, g, total, pack);
+    hipLaunchKernelGGL(x3_bwx_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, W, H, Hp, m, g, total,
+                       x3_absmax_blocks(nW), pack);
     return xdfm_check_launch("cin_bwd_pack (f16x3)");
 }
 

@@ -4,7 +4,7 @@
 // rows j (row maxima by one reduction pass).  dOut is split once into fp16 hi / lo planes (it is the A
 // operand of every one of the K/32 column tiles); Z = xp*x0 is formed, scaled and split in registers.
 //
-//   pass 1  x3_rowmax_kernel      row maxima of dOut, x_prev, x0                 -> workspace header
+//   pass 1  x3_rowmax_kernel      partial row maxima of dOut, x_prev, x0, then x3_rowscale_kernel -> scales
 //   pass 2  x3_split_dout_kernel  dOut * sD[h] -> planes [Hpad][NP/32][hi 32 | lo 32] fp16 (zero padded)
 //   pass 3  cin_bwd_w_x3_kernel   MFMA; per n-split slabs (same tiling as the fp32 kernel)
 //   pass 4  x3_bww_unpack_kernel  ordered sum of the slabs, scales removed, [h][i*m+j] layout
@@ -30,27 +30,29 @@ bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, l
            ((((size_t)dOut) | ((size_t)xp) | ((size_t)x0)) & 15) == 0;
 }
 
-struct X3BwwWs { long hdr, planes, NP; };     // element (float) counts of the workspace parts
-static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int m, long N) {
+#define X3_RM_COLS 16384      // columns per block of the row-maximum pass
+struct X3BwwWs { long hdr, parts, planes, NP; int nbx; };     // element (float) counts of the workspace parts
+static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int H, int Hp, int m, long N) {
     X3BwwWs w;
     w.NP = round_up(N, 32);
-    w.hdr = round_up((long)g.Hpad + g.IPAD + m, 64);
+    w.nbx = ceil_div(N, X3_RM_COLS);
+    w.hdr = round_up((long)g.Hpad + g.IPAD + m, 64);               // scales: dOut rows, x_prev rows, x0 rows
+    w.parts = round_up((long)(H + Hp + m) * w.nbx, 64);            // per-block partial row maxima
     w.planes = (long)g.Hpad * w.NP;
     return w;
 }
 
 // ---------------------------------------------------------------------------------------------
-// rows [0, H) of dOut, [H, H+Hp) of xp, [H+Hp, H+Hp+m) of x0 -> hdr[0..Hpad), hdr[Hpad..Hpad+IPAD), hdr[Hpad+IPAD..)
-#define X3_RM_COLS 16384      // columns per block of the row-maximum pass
+// Row maxima without atomics or zero-initialised cells (nothing depends on a memset node inside a captured
+// graph): block (bx, row) stores the maximum of its X3_RM_COLS columns in parts[row*nbx + bx]; rows [0, H) are
+// dOut, [H, H+Hp) x_prev, [H+Hp, H+Hp+m) x0.  x3_rowscale_kernel reduces the partials to the power-of-two
+// scales hdr[0..Hpad) (dOut, < 2^15), hdr[Hpad..Hpad+IPAD) (x_prev, < 2^7), hdr[Hpad+IPAD..) (x0, < 2^7);
+// rows outside the matrices get scale 1.
 __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict__ dOut, const float* __restrict__ xp,
-                                                       const float* __restrict__ x0, int H, int Hp, int m, long N,
-                                                       int Hpad, int IPAD, unsigned* __restrict__ hdr) {
+                                                       const float* __restrict__ x0, int H, int Hp, long N,
+                                                       float* __restrict__ parts) {
     const int row = blockIdx.y;
-    const float* src;
-    unsigned* dst;
-    if (row < H) { src = dOut + (long)row * N; dst = hdr + row; }
-    else if (row < H + Hp) { src = xp + (long)(row - H) * N; dst = hdr + Hpad + (row - H); }
-    else { src = x0 + (long)(row - H - Hp) * N; dst = hdr + Hpad + IPAD + (row - H - Hp); }
+    const float* src = row < H ? dOut + (long)row * N : (row < H + Hp ? xp + (long)(row - H) * N : x0 + (long)(row - H - Hp) * N);
     float v = 0.f;
     const long base = (long)blockIdx.x * X3_RM_COLS;
 #pragma unroll 4
@@ -65,15 +67,26 @@ __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict_
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        if (v > 0.f) atomicMax(dst, __float_as_uint(v));           // one atomic per block
-    }
+    if (threadIdx.x == 0) parts[(long)row * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ void x3_rowscale_kernel(const float* __restrict__ parts, int nbx, int H, int Hp, int m, int Hpad, int IPAD,
+                                   float* __restrict__ hdr) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Hpad + IPAD + m) return;
+    int row = -1, target = 15;
+    if (t < Hpad) { if (t < H) row = t; }
+    else if (t < Hpad + IPAD) { target = 7; if (t - Hpad < Hp) row = H + (t - Hpad); }
+    else { target = 7; row = H + Hp + (t - Hpad - IPAD); }
+    float mx = 0.f;
+    if (row >= 0)
+        for (int k = 0; k < nbx; ++k) mx = fmaxf(mx, parts[(long)row * nbx + k]);
+    hdr[t] = x3w_pow2_scale(mx, target);
 }
 
 // one thread = 8 columns of one row: 128-B blocks [hi 32 halves | lo 32 halves] per 32 columns
 __global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restrict__ dOut, int H, long N, long NP,
-                                                           const unsigned* __restrict__ hdr, char* __restrict__ planes) {
+                                                           const float* __restrict__ hdr, char* __restrict__ planes) {
     const int row = blockIdx.y;
     const long n = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
     if (n >= NP) return;
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = 0.f;
     if (row < H) {
-        const float s = x3w_pow2_scale(__uint_as_float(hdr[row]), 15);
+        const float s = hdr[row];
         const float* src = dOut + (long)row * N + n;
         if (n < N) { const float4 a = *reinterpret_cast<const float4*>(src); v[0] = a.x * s; v[1] = a.y * s; v[2] = a.z * s; v[3] = a.w * s; }
         if (n + 4 < N) { const float4 a = *reinterpret_cast<const float4*>(src + 4); v[4] = a.x * s; v[5] = a.y * s; v[6] = a.z * s; v[7] = a.w * s; }
@@ -117,7 +130,7 @@ __device__ __forceinline__ void x3w_split2(float z0, float z1, h2& hi, h2& lo) {
 template <int MT>
 __global__ __launch_bounds__(256, 2) void cin_bwd_w_x3_kernel(
     const char* __restrict__ planes, long PB, const float* __restrict__ xp, const float* __restrict__ x0,
-    const unsigned* __restrict__ hdr, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
+    const float* __restrict__ hdr, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
     int IPAD, float* __restrict__ dWt, long slab_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int JT = 2;
@@ -174,11 +187,11 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_x3_kernel(
     float fz[JT];
     {
         const int i = iblk * 32 + r;
-        const float sx = x3w_pow2_scale(__uint_as_float(hdr[Hpad + (i < IPAD ? i : 0)]), 7);
+        const float sx = hdr[Hpad + (i < IPAD ? i : 0)];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             const int j = jp * JT + jt;
-            fz[jt] = (i < Hp && j < m) ? sx * x3w_pow2_scale(__uint_as_float(hdr[Hpad + IPAD + (j < m ? j : 0)]), 7) : 0.f;
+            fz[jt] = (i < Hp && j < m) ? sx * hdr[Hpad + IPAD + (j < m ? j : 0)] : 0.f;
         }
     }
 
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_x3_kernel(
 }
 
 // dW[h][i*m+j] = (sum over n-splits of dWt[split][j][h][i]) / (sD[h] * sxp[i] * sx0[j])
-__global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const unsigned* __restrict__ hdr, int H, int Hp, int m,
+__global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const float* __restrict__ hdr, int H, int Hp, int m,
                                      int Hpad, int IPAD, int nslab, long slab_stride, float* __restrict__ dW) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)m * Hpad * IPAD;
@@ -279,31 +292,29 @@ __global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const unsign
     if (i >= Hp || h >= H) return;
     float acc = 0.f;
     for (int k = 0; k < nslab; ++k) acc += dWt[(long)k * slab_stride + idx];
-    const float sd = x3w_pow2_scale(__uint_as_float(hdr[h]), 15);
-    const float sx = x3w_pow2_scale(__uint_as_float(hdr[Hpad + i]), 7);
-    const float sz = x3w_pow2_scale(__uint_as_float(hdr[Hpad + IPAD + j]), 7);
+    const float sd = hdr[h], sx = hdr[Hpad + i], sz = hdr[Hpad + IPAD + j];
     dW[(long)h * ((long)Hp * m) + (long)i * m + j] = acc * (1.f / sd) * (1.f / sx) * (1.f / sz);
 }
 
 // ---------------------------------------------------------------------------------------------
 size_t x3_bww_ws_elems(int H, int Hp, int m, long N) {
     const BwwGeom g = bww_geometry(H, Hp, m, N);
-    const X3BwwWs w = x3_bww_ws(g, m, N);
-    return (size_t)w.hdr + (size_t)w.planes + (size_t)g.slab * g.nsplit;
+    const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);
+    return (size_t)w.hdr + (size_t)w.parts + (size_t)w.planes + (size_t)g.slab * g.nsplit;
 }
 
 int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
                    float* dW, hipStream_t st) {
     BwwGeom g = bww_geometry(H, Hp, m, N);
-    const X3BwwWs w = x3_bww_ws(g, m, N);
+    const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);
     if ((((size_t)ws) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_w: workspace must be 16-byte aligned");
-    unsigned* hdr = reinterpret_cast<unsigned*>(ws);
-    char* planes = reinterpret_cast<char*>(ws + w.hdr);
-    float* slabs = ws + w.hdr + w.planes;
-    hipError_t e = hipMemsetAsync(hdr, 0, (size_t)w.hdr * sizeof(float), st);
-    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "cin_level_bwd_w memset: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(x3_rowmax_kernel, dim3(ceil_div(N, X3_RM_COLS), H + Hp + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, m, N,
-                       g.Hpad, g.IPAD, hdr);
+    float* hdr = ws;
+    float* parts = ws + w.hdr;
+    char* planes = reinterpret_cast<char*>(ws + w.hdr + w.parts);
+    float* slabs = ws + w.hdr + w.parts + w.planes;
+    hipLaunchKernelGGL(x3_rowmax_kernel, dim3(w.nbx, H + Hp + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, N, parts);
+    hipLaunchKernelGGL(x3_rowscale_kernel, dim3(ceil_div(g.Hpad + g.IPAD + m, 256)), dim3(256), 0, st, parts, w.nbx, H, Hp,
+                       m, g.Hpad, g.IPAD, hdr);
     hipLaunchKernelGGL(x3_split_dout_kernel, dim3(ceil_div(w.NP, 2048), g.Hpad), dim3(256), 0, st, dOut, H, N, w.NP, hdr,
                        planes);
     int rc = xdfm_check_launch("cin_level_bwd_w split");

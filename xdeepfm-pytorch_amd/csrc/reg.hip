@@ -115,3 +115,51 @@ int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* co
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Column sums of a row-major [rows][cols] matrix: the bias gradient of a dense layer
+// (autograd of deepctr/layers/core.py:120-134: grad_bias = grad_output.sum(0)).  ATen's multi-block
+// reduction zeroes a semaphore buffer with hipMemsetAsync first; a memset node inside a captured HIP
+// graph is not reliably ordered against its neighbouring kernel nodes on this stack
+// (tools/graph_memset_probe.py: 3 of 4 replays wrong), so the train step uses this two-launch,
+// atomics-free, fixed-order version instead.
+#define CS_ROWBLK 16
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, long rows, int cols, long ld,
+                                                            float* __restrict__ part) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;                         // 4 row groups per block
+    const long per = (rows + CS_ROWBLK - 1) / CS_ROWBLK;
+    const long r0 = (long)blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    float a = 0.f;
+    if (c < cols)
+        for (long r = r0 + rg; r < r1; r += 4) a += g[r * ld + c];
+    __shared__ float red[4][64];
+    red[rg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rg == 0 && c < cols)
+        part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_ROWBLK; ++k) s += part[(long)k * cols + c];
+    out[c] = s;
+}
+
+extern "C" {
+
+size_t xdfm_colsum_ws_elems(int cols) { return cols > 0 ? (size_t)CS_ROWBLK * cols : 0; }
+
+int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* out, void* stream) {
+    XDFM_REQUIRE(g && ws && out, "colsum: null pointer");
+    XDFM_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "colsum: bad shape rows=%ld cols=%d ld=%ld", rows, cols, ld);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 64), CS_ROWBLK), dim3(256), 0, st, g, rows, cols, ld, ws);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, ws, cols, out);
+    return xdfm_check_launch("colsum");
+}
+
+}  // extern "C"

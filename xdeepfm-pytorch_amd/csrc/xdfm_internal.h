@@ -63,7 +63,7 @@ static inline int bwx_hs4(int H) {      // float4 groups along the contraction (
 __device__ __forceinline__ int frag_row(int r, int s) { return (r & 3) + 8 * (r >> 2) + 4 * s; }
 
 // ---- f16x3 path (cin_x3*.hip) ------------------------------------------------------------------
-#define X3_HDR 64         // floats in front of a packed weight stream: [0] scale, [1] 1/scale, [2] max|W| bits
+#define X3_HDR 128        // floats in front of a packed weight stream: [0] scale, [1] 1/scale, [64..127] partial maxima of |W|
 struct X3Geom {
     int MT, MB;           // row tiles (of 32) per wave, row groups (blockIdx.y)
     int MP;               // MFMA steps per full block of 8 x_prev rows (= m / 2)

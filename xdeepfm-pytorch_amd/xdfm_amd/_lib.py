@@ -23,6 +23,7 @@ SIGNATURES = {
     "xdfm_device_count": (c_int, []),
     "xdfm_set_option": (c_int, [c_char_p, c_int]),
     "xdfm_get_option": (c_int, [c_char_p]),
+    "xdfm_graph_node_census": (c_int, [P, P, P, P]),
     "xdfm_embed_gather_fwd": (c_int, [P, c_long, c_int, P, P, P, P, c_int, c_int, P, P, c_int, P, P, P, P, P]),
     "xdfm_embed_scatter_bwd": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P]),
     "xdfm_cin_fwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
@@ -39,6 +40,8 @@ SIGNATURES = {
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
+    "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
     "xdfm_l2_reg_fwd": (c_int, [P, P, P, c_int, P, P, P]),
     "xdfm_l2_reg_bwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
 }

@@ -204,7 +204,8 @@ class CINAttentionV2(_CINBase):
 
 class DNN(nn.Module):
     """ReLU / linear MLP (deepctr/layers/core.py:67-134).  The GEMMs are far below 2 % of the step's
-    FLOPs and go to hipBLASLt through torch; Dice / PReLU belong to other models of the zoo."""
+    FLOPs and go to hipBLASLt through torch (ops.Dense: bias gradient by the library's memset-free column
+    sum, so that the step can be captured in a HIP graph); Dice / PReLU belong to other models of the zoo."""
 
     def __init__(self, inputs_dim, hidden_units, activation='relu', l2_reg=0, dropout_rate=0, use_bn=False,
                  init_std=0.0001, dice_dim=3, seed=1024, device='cpu'):
@@ -227,7 +228,7 @@ class DNN(nn.Module):
 
     def forward(self, x):
         for i, lin in enumerate(self.linears):
-            x = lin(x)
+            x = ops.dense(x, lin.weight, lin.bias)
             if self.use_bn:
                 x = self.bn[i](x)
             if self.activation == "relu":

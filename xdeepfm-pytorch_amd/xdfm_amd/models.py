@@ -267,7 +267,16 @@ class BaseModel(nn.Module):
     def train_on_batch(self, x, y):
         """One optimisation step = the body of the reference's batch loop (basemodel.py:245-262):
         forward, BCE(sum) + L2 (+ aux), backward, optimizer step.  Returns (y_pred, data_loss,
-        total_loss) as device tensors -- no host synchronisation."""
+        total_loss) as device tensors -- no host synchronisation.  On a GPU, from the third step of a
+        batch shape on, the step is replayed from a captured HIP graph (xdfm_amd/graphstep.py); the
+        returned tensors are then the graph's static outputs, valid until the next call."""
+        step = self.__dict__.get("_graphed_step")
+        if step is None:
+            from .graphstep import GraphedStep
+            step = self.__dict__["_graphed_step"] = GraphedStep(self)
+        return step(x, y)
+
+    def _train_step_eager(self, x, y):
         y_pred = self(x).squeeze()
         self.optim.zero_grad()
         loss_func = self.loss_func
@@ -293,7 +302,9 @@ class BaseModel(nn.Module):
             (reg_d + self.aux_loss).backward()
             total_loss = loss.detach() + reg_t.detach() + reg_d.detach() + self.aux_loss
         self.optim.step()
-        return y_pred, loss, total_loss
+        # detached: a caller that keeps these alive must not keep the step's autograd graph (and with it the
+        # parameters' AccumulateGrad nodes and their stream) alive into the next step
+        return y_pred.detach(), loss.detach(), total_loss.detach()
 
     def add_auxiliary_loss(self, aux_loss, alpha):
         self.aux_loss = aux_loss * alpha
@@ -301,6 +312,7 @@ class BaseModel(nn.Module):
     # ------------------------------------------------------------------ compile
     def compile(self, optimizer, loss=None, metrics=None):
         self.metrics_names = ["loss"]
+        self._optim_capturable = False
         self.optim = self._get_optim(optimizer)
         self.loss_func = self._get_loss_func(loss)
         self.metrics = self._get_metrics(metrics)
@@ -312,7 +324,9 @@ class BaseModel(nn.Module):
             # same update rule as basemodel.py:452; on a GPU use torch's single-pass multi-tensor kernel
             params = list(params)
             on_gpu = len(params) > 0 and all(p.is_cuda for p in params)
-            return torch.optim.Adam(params, fused=True) if on_gpu else torch.optim.Adam(params)
+            # capturable: the step counters live on the device, so the step can be replayed from a HIP graph
+            self._optim_capturable = on_gpu
+            return torch.optim.Adam(params, fused=True, capturable=True) if on_gpu else torch.optim.Adam(params)
         table = {"sgd": lambda p: torch.optim.SGD(p, lr=0.01), "adam": adam,
                  "adagrad": torch.optim.Adagrad, "rmsprop": torch.optim.RMSprop}
         if optimizer not in table:

@@ -399,6 +399,43 @@ def attn_pool(fm, B, D, mhsa_layers, layer_norms, pooling, use_res):
 
 
 # --------------------------------------------------------------------------------------------- #
+# dense layer                                                                                    #
+# --------------------------------------------------------------------------------------------- #
+class Dense(torch.autograd.Function):
+    """y = x W^T + b (deepctr/layers/core.py:120-134).  The three GEMMs stay with hipBLASLt; the bias
+    gradient is the library's own column sum, because ATen's `sum(0)` zeroes a semaphore buffer with
+    hipMemsetAsync and a memset node inside a captured HIP graph is not ordered reliably on this stack
+    (tools/graph_memset_probe.py) -- with it the train step contains no memset at all."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, W, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = g.contiguous()
+        dx = g.mm(W) if ctx.needs_input_grad[0] else None
+        dW = g.t().mm(x) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            lib = _lib.load()
+            rows, cols = g.shape
+            ws = torch.empty(lib.xdfm_colsum_ws_elems(cols), dtype=torch.float32, device=g.device)
+            db = torch.empty(cols, dtype=torch.float32, device=g.device)
+            _lib.check(lib.xdfm_colsum(_ptr(g), rows, cols, g.stride(0), _ptr(ws), _ptr(db), _stream()), "colsum")
+        return dx, dW, db
+
+
+def dense(x, W, b):
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32:
+        return Dense.apply(x, W, b)
+    return torch.nn.functional.linear(x, W, b)
+
+
+# --------------------------------------------------------------------------------------------- #
 # L2 regulariser                                                                                 #
 # --------------------------------------------------------------------------------------------- #
 class L2Plan:
