@@ -189,6 +189,16 @@ int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* co
 size_t xdfm_colsum_ws_elems(int cols);
 int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* out, void* stream);
 
+/* ------------------------------------------------------------------ Adam over the tables (K7)
+ * replaces: torch.optim.Adam.step() (deepctr/models/basemodel.py:452) for the embedding / linear tables, whose
+ * gradients are dense (deepctr/inputs.py:168): one streaming launch, arithmetic of ATen's fused Adam in fp32.
+ * params / exp_avg / exp_avg_sq: device arrays of T tensor base pointers; steps: device array of T pointers to
+ * the fp32 step counters (already incremented for this step); numel: device long[T];
+ * gradient of tensor t = gbase + goff[t] (device long[T], the layout xdfm_embed_scatter_bwd fills). */
+int xdfm_adam_tables(float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                     const float* const* steps, const long* numel, int T, const float* gbase, const long* goff,
+                     double lr, double beta1, double beta2, double eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

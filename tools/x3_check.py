@@ -92,6 +92,9 @@ def timing(B, m, D, ls, do_bwd=True):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "time":                      # full-size launches only (for rocprofv3 --pmc runs)
+        timing(4096, 26, 16, (256, 128, 128), do_bwd=True)
+        sys.exit(0)
     bwd = what != "fwd"
     run(130, 26, 16, (64, 32, 32), do_bwd=bwd)
     run(257, 26, 8, (128, 128), do_bwd=bwd)

@@ -1,0 +1,81 @@
+// K7: Adam step over the embedding tables (one launch for all tables of the gather).
+//
+// replaces torch.optim.Adam.step() for the [vocab, D] / [vocab, 1] tables (deepctr/models/basemodel.py:452
+// builds torch.optim.Adam over every parameter; the reference's tables carry dense gradients,
+// deepctr/inputs.py:168 sparse=False, so every row is updated every step).  44 M parameters at config 2 =
+// 1.2 GB of traffic per step (p, m, v read + written, g read): pure HBM streaming, 16-byte accesses, 8 loads
+// in flight per thread.  Arithmetic follows ATen's fused kernel (fused_adam_utils.cuh), in fp32:
+//   m = m + (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// The gradients of all tables live in one flat buffer (gbase + goff[t]); the step counters are the
+// device-resident fp32 scalars torch keeps per parameter (already incremented by the caller).
+#include "xdfm_internal.h"
+
+#define ADAM_THREADS 256
+#define ADAM_BX 128
+
+struct AdamCoef { float w1, b2, w2, lr, eps; };
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt, const AdamCoef& c) {
+    m = m + c.w1 * (g - m);
+    v = c.b2 * v + c.w2 * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + c.eps;
+    p -= step_size * m / denom;
+}
+
+__global__ __launch_bounds__(ADAM_THREADS) void adam_tables_kernel(
+    float* const* __restrict__ ps, float* const* __restrict__ ms, float* const* __restrict__ vs,
+    const float* const* __restrict__ steps, const long* __restrict__ numel, const float* __restrict__ gbase,
+    const long* __restrict__ goff, double lr, double beta1, double beta2, double eps) {
+    const int t = blockIdx.y;
+    float* __restrict__ p = ps[t];
+    float* __restrict__ m = ms[t];
+    float* __restrict__ v = vs[t];
+    const float* __restrict__ g = gbase + goff[t];
+    const long n = numel[t];
+    const double step = (double)*steps[t];
+    const double bc1 = 1.0 - pow(beta1, step);
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, step));
+    const float step_size = (float)(lr / bc1);
+    const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)lr, (float)eps};
+    const long tid = (long)blockIdx.x * ADAM_THREADS + threadIdx.x;
+    const long stride = (long)ADAM_BX * ADAM_THREADS;
+    const bool vec = ((((size_t)p) | ((size_t)m) | ((size_t)v) | ((size_t)g)) & 15) == 0;
+    const long n4 = vec ? n / 4 : 0;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    long i = tid;
+    for (; i + stride < n4; i += 2 * stride) {            // two float4 per array in flight
+        float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+        float4 pb = p4[i + stride], gb = g4[i + stride], mb = m4[i + stride], vb = v4[i + stride];
+        adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+        adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+        adam_one(pb.x, gb.x, mb.x, vb.x, step_size, bc2_sqrt, c); adam_one(pb.y, gb.y, mb.y, vb.y, step_size, bc2_sqrt, c);
+        adam_one(pb.z, gb.z, mb.z, vb.z, step_size, bc2_sqrt, c); adam_one(pb.w, gb.w, mb.w, vb.w, step_size, bc2_sqrt, c);
+        p4[i] = pa; m4[i] = ma; v4[i] = va;
+        p4[i + stride] = pb; m4[i + stride] = mb; v4[i + stride] = vb;
+    }
+    for (; i < n4; i += stride) {
+        float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+        adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+        adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+        p4[i] = pa; m4[i] = ma; v4[i] = va;
+    }
+    for (long k = 4 * n4 + tid; k < n; k += stride) {
+        float pa = p[k], ma = m[k], va = v[k];
+        adam_one(pa, g[k], ma, va, step_size, bc2_sqrt, c);
+        p[k] = pa; m[k] = ma; v[k] = va;
+    }
+}
+
+extern "C" int xdfm_adam_tables(float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                                const float* const* steps, const long* numel, int T, const float* gbase,
+                                const long* goff, double lr, double beta1, double beta2, double eps, void* stream) {
+    XDFM_REQUIRE(params && exp_avg && exp_avg_sq && steps && numel && gbase && goff, "adam_tables: null pointer");
+    XDFM_REQUIRE(T > 0 && T <= 65535, "adam_tables: bad tensor count %d", T);
+    XDFM_REQUIRE(lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "adam_tables: bad hyper-parameters");
+    hipLaunchKernelGGL(adam_tables_kernel, dim3(ADAM_BX, T), dim3(ADAM_THREADS), 0, (hipStream_t)stream, params, exp_avg,
+                       exp_avg_sq, steps, numel, gbase, goff, lr, beta1, beta2, eps);
+    return xdfm_check_launch("adam_tables");
+}

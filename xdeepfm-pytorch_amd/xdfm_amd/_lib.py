@@ -5,7 +5,7 @@ import of any op fails with an explicit error, and every op refuses non-CUDA ten
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_int, c_long, c_size_t, c_void_p
 
 # torch must be imported BEFORE the library is dlopen'ed: the torch wheel bundles its own
 # libamdhip64 and the process must end up with ONE HIP runtime (the one that owns torch's device
@@ -40,6 +40,7 @@ SIGNATURES = {
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "xdfm_adam_tables": (c_int, [P, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_double, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
     "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
     "xdfm_l2_reg_fwd": (c_int, [P, P, P, c_int, P, P, P]),

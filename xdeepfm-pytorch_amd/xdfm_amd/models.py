@@ -326,7 +326,10 @@ class BaseModel(nn.Module):
             on_gpu = len(params) > 0 and all(p.is_cuda for p in params)
             # capturable: the step counters live on the device, so the step can be replayed from a HIP graph
             self._optim_capturable = on_gpu
-            return torch.optim.Adam(params, fused=True, capturable=True) if on_gpu else torch.optim.Adam(params)
+            if on_gpu:
+                from .optim import TableAdam
+                return TableAdam(params)
+            return torch.optim.Adam(params)
         table = {"sgd": lambda p: torch.optim.SGD(p, lr=0.01), "adam": adam,
                  "adagrad": torch.optim.Adagrad, "rmsprop": torch.optim.RMSprop}
         if optimizer not in table:
