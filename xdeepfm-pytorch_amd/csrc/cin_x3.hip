@@ -32,6 +32,8 @@ X3Geom x3_fwd_geom(int H, int Hp, int m) {
     X3Geom g;
     const int t = ceil_div(H, 32);
     g.MT = t >= 8 ? 8 : (t > 2 ? 4 : 2);
+    const int o = xdfm_opt(OPT_X3_FWD_MT);          // A/B knob: cap the row tiles per wave (more, smaller workgroups)
+    if ((o == 2 || o == 4) && g.MT > o) g.MT = o;
     g.MB = ceil_div(H, 32 * g.MT);
     g.MP = m / 2;
     g.FB = Hp / 8;
@@ -148,19 +150,20 @@ __global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, i
 // 32 columns and all MT row tiles.  The packed weight fragments of one step (2*MT KB) are shared by the
 // four waves through a 3-deep LDS ring filled by 16-byte LDS-DMA two steps ahead (one counted
 // s_waitcnt vmcnt + raw s_barrier per step); each wave builds its own B operand (Z hi / lo) in registers.
-template <int MT, int M>
-__global__ __launch_bounds__(256, 2) void cin_fwd_x3_kernel(
+template <int MT, int M, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ pack,
     const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MP = M / 2;
     constexpr int FR = 2 * MT;                  // 1-KB fragments per stage
     constexpr int STAGE = FR * 1024;            // bytes
-    constexpr int FPW = FR / 4;                 // LDS-DMA instructions per wave and stage
+    constexpr int FPW = FR / NW;                // LDS-DMA instructions per wave and stage
+    static_assert(FR % NW == 0, "every wave issues the same number of LDS-DMA pieces");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, hh = lane >> 5;
-    const long n = ((long)blockIdx.x * 4 + wave) * 32 + c;
+    const long n = ((long)blockIdx.x * NW + wave) * 32 + c;
     const bool nok = n < N;                     // no early exit: every wave feeds the ring and the barriers
     const long nc = nok ? n : N - 1;
     const float nmask = nok ? 1.f : 0.f;
@@ -315,12 +318,19 @@ int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
     return xdfm_check_launch("cin_fwd_pack (f16x3)");
 }
 
+// NW waves (= 32*NW columns) share one weight ring: 8 waves halve the L2 -> LDS traffic of the ring (every
+// workgroup streams the whole packed matrix: 512 x 1.7 MB per launch at config 2 with 4 waves)
 template <int MT, int M>
 static int launch_x3(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, long N,
                      const X3Geom& g, int act, float* out, hipStream_t st) {
     const size_t lds = (size_t)3 * 2 * MT * 1024;
-    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds, st, xp, x0, pack, bias, H,
-                       Hp, N, g, act, out);
+    constexpr int NWMAX = (2 * MT) % 8 == 0 ? 8 : 4;
+    if (NWMAX == 8 && xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64)
+        hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX>), dim3(ceil_div(N, 32 * NWMAX), g.MB), dim3(64 * NWMAX), lds, st,
+                           xp, x0, pack, bias, H, Hp, N, g, act, out);
+    else
+        hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds, st, xp, x0, pack,
+                           bias, H, Hp, N, g, act, out);
     return xdfm_check_launch("cin_level_fwd (f16x3)");
 }
 
@@ -390,19 +400,20 @@ __global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, i
     dst[64] = lo;
 }
 
-template <int HBT>
-__global__ __launch_bounds__(256, 2) void cin_bwd_x3_kernel(
+template <int HBT, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
     const float* __restrict__ dOut, const float* xp, const float* x0, const float* __restrict__ pack,
     int H, int Hp, int m, long N, int IB, float* dxp, float* dx0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HBS = HBT > 8 ? 8 : HBT;      // h-blocks per stage
     constexpr int SPT = HBT / HBS;              // stages per tile
     constexpr int STAGE = HBS * 2048;
-    constexpr int FPW = HBS * 2 / 4;
+    constexpr int FPW = HBS * 2 / NW;
+    static_assert((HBS * 2) % NW == 0, "every wave issues the same number of LDS-DMA pieces");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, hh = lane >> 5;
-    const long n0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const long n0 = ((long)blockIdx.x * NW + wave) * 32;
     const long n = n0 + c;
     const bool nok = n < N;
     const long nc = nok ? n : N - 1;
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_x3_kernel(
     dma_stage(wsrc + STAGE, STAGE);
 
     float* x0s = reinterpret_cast<float*>(smem + 3 * STAGE) + wave * (m * 32);     // wave-private x0[j][n0..n0+31]
-    float* dx0s = reinterpret_cast<float*>(smem + 3 * STAGE) + (4 + wave) * (m * 32);
+    float* dx0s = reinterpret_cast<float*>(smem + 3 * STAGE) + (NW + wave) * (m * 32);
     for (int idx = lane; idx < m * 32; idx += 64) {
         const long nn = n0 + (idx & 31);
         x0s[idx] = x0[(long)(idx >> 5) * N + (nn < N ? nn : N - 1)];
@@ -525,10 +536,16 @@ template <int HBT>
 static int launch_bwx3(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m,
                        long N, const X3BwxGeom& g, float* dxp, float* dx0, hipStream_t st) {
     constexpr int HBS = HBT > 8 ? 8 : HBT;
-    const size_t lds = (size_t)3 * HBS * 2048 + (size_t)8 * m * 32 * sizeof(float);
-    if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds);
-    hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, pack, H, Hp, m,
-                       N, g.IB, dxp, dx0);
+    constexpr int NWMAX = (HBS * 2) % 8 == 0 ? 8 : 4;
+    const size_t lds8 = (size_t)3 * HBS * 2048 + (size_t)2 * NWMAX * m * 32 * sizeof(float);
+    const size_t lds4 = (size_t)3 * HBS * 2048 + (size_t)8 * m * 32 * sizeof(float);
+    if (lds4 > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds4);
+    if (NWMAX == 8 && xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64 && lds8 <= 160 * 1024)
+        hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, NWMAX>), dim3(ceil_div(N, 32 * NWMAX)), dim3(64 * NWMAX), lds8, st, dOut, xp,
+                           x0, pack, H, Hp, m, N, g.IB, dxp, dx0);
+    else
+        hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, 4>), dim3(ceil_div(N, 128)), dim3(256), lds4, st, dOut, xp, x0, pack, H, Hp,
+                           m, N, g.IB, dxp, dx0);
     return xdfm_check_launch("cin_level_bwd_x (f16x3)");
 }
 

@@ -123,7 +123,7 @@ int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* co
 // graph is not reliably ordered against its neighbouring kernel nodes on this stack
 // (tools/graph_memset_probe.py: 3 of 4 replays wrong), so the train step uses this two-launch,
 // atomics-free, fixed-order version instead.
-#define CS_ROWBLK 16
+#define CS_ROWBLK 64
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, long rows, int cols, long ld,
                                                             float* __restrict__ part) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);

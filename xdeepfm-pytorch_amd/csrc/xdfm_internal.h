@@ -20,6 +20,9 @@ enum {
     OPT_BWW_MT,          // 0 = auto; 1/2/4 = row tiles (of 32) per wave in the dW kernel
     OPT_DBG,             // timing experiments only (results become wrong): bit0 = A operand from one cached line
     OPT_CIN_MATH,        // 0 = v_mfma_f32_32x32x2_f32 on fp32 operands; 1 = f16x3 split (cin_x3*.hip) where a kernel exists
+    OPT_X3_FWD_MT,       // 0 = auto; 2 / 4 = at most that many row tiles per wave in the f16x3 forward kernel
+    OPT_X3_BWX_ROWS,     // 0 = auto (256); rows of the contraction per f16x3 dX launch (host side reads it)
+    OPT_X3_WAVES,        // 0 = auto (8 waves per workgroup share a weight ring where the piece count allows); 4 = force 4
     OPT_COUNT
 };
 

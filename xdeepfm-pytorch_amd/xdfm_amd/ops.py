@@ -293,8 +293,9 @@ class CINStack(torch.autograd.Function):
             # dX: H <= 256 rows of the contraction per launch
             dxp = torch.zeros((Hp, N), dtype=torch.float32, device=dev)
             W2 = W.reshape(H, Hp * m)
-            for h0 in range(0, H, 256):
-                hc = min(256, H - h0)
+            hstep = _lib.get_option("x3_bwx_rows") or 256          # rows of the contraction per launch (<= 256)
+            for h0 in range(0, H, hstep):
+                hc = min(hstep, H - h0)
                 wz = torch.empty(lib.xdfm_cin_bwd_pack_elems(hc, Hp, m), dtype=torch.float32, device=dev)
                 wc = W2[h0:h0 + hc].contiguous()
                 _lib.check(lib.xdfm_cin_bwd_pack(_ptr(wc), hc, Hp, m, _ptr(wz), _stream()), "cin_bwd_pack")
