@@ -136,6 +136,11 @@ size_t xdfm_cin_bwd_pack_elems(int H, int Hp, int m);
 int xdfm_cin_bwd_pack(const float* W, int H, int Hp, int m, float* Wz, void* stream);
 int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz,
                          int H, int Hp, int m, long N, float* dxp, float* dx0, void* stream);
+/* same with flags: XDFM_BWX_SET_DXP / XDFM_BWX_SET_DX0 = store the result instead of adding it to dxp / dx0
+ * (the buffer then needs no zero-fill and is not read). */
+enum { XDFM_BWX_SET_DXP = 1, XDFM_BWX_SET_DX0 = 2 };
+int xdfm_cin_level_bwd_x_ex(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
+                            int m, long N, float* dxp, float* dx0, int flags, void* stream);
 
 /* dW[h][i*m+j] = sum_n dOut[h][n] * x_prev[i][n] * x0[j][n]   (overwrites dW [H][Hp*m]).
  * ws: workspace of xdfm_cin_bwd_w_ws_elems floats (one partial copy of dW per n-split, summed in a
@@ -194,10 +199,15 @@ int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* 
  * gradients are dense (deepctr/inputs.py:168): one streaming launch, arithmetic of ATen's fused Adam in fp32.
  * params / exp_avg / exp_avg_sq: device arrays of T tensor base pointers; steps: device array of T pointers to
  * the fp32 step counters (already incremented for this step); numel: device long[T];
- * gradient of tensor t = gbase + goff[t] (device long[T], the layout xdfm_embed_scatter_bwd fills). */
+ * gradient of tensor t = gbase + goff[t] (device long[T], the layout xdfm_embed_scatter_bwd fills).
+ * l2 (device float[T] or NULL): L2 strengths; the kernel then uses g + 2 l2[t] w as the gradient (the term
+ * l2[t] * sum(w^2) of basemodel.py:412-428 with unit upstream gradient), and with l2_value != NULL also returns
+ * sum_t l2[t] * sum(w_t^2) of the weights BEFORE the update (l2_ws: xdfm_adam_tables_ws_elems(T) floats). */
+size_t xdfm_adam_tables_ws_elems(int T);
 int xdfm_adam_tables(float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
                      const float* const* steps, const long* numel, int T, const float* gbase, const long* goff,
-                     double lr, double beta1, double beta2, double eps, void* stream);
+                     double lr, double beta1, double beta2, double eps,
+                     const float* l2, float* l2_ws, float* l2_value, void* stream);
 
 #ifdef __cplusplus
 }

@@ -610,8 +610,9 @@ def test_table_adam_kernel_matches_torch_adam():
     init = [torch.randn(s, device=dev) * 0.05 for s in shapes]
     pa = [torch.nn.Parameter(t.clone()) for t in init]
     pb = [torch.nn.Parameter(t.clone()) for t in init]
-    oa = TableAdam(pa, lr=2e-3)
+    oa = TableAdam(pa, lr=2e-3, tables=pa[:3])                                # K7 for the three "tables"
     ob = torch.optim.Adam(pb, lr=2e-3, fused=True)
+    l2 = [1e-3, 0.0, 5e-2]
     sizes = [p.numel() for p in pa]
     for step in range(6):
         flat = torch.randn(sum(sizes) + 8, device=dev) * (0.1 if step % 2 else 1e-3)
@@ -621,8 +622,17 @@ def test_table_adam_kernel_matches_torch_adam():
             p.grad = flat[off:off + n].view(p.shape)
             q.grad = flat[off:off + n].view(p.shape).clone()
             off += n
+        if step % 2:                   # every other step with the L2 term armed: K7 adds 2*l2*w and returns the value
+            oa.arm_table_l2(pa[:3], l2)
+            want_value = sum(c * float((q.detach().double() ** 2).sum()) for q, c in zip(pb[:3], l2))
+            for q, c in zip(pb[:3], l2):
+                q.grad.add_(q.detach(), alpha=2 * c)
         oa.step()
         ob.step()
+        if step % 2:
+            assert abs(float(oa.table_l2_value) - want_value) <= 1e-5 * want_value
+        else:
+            assert oa.table_l2_value is None
     for i, (p, q) in enumerate(zip(pa, pb)):
         close(p, q.detach().cpu().numpy(), rtol=2e-6, atol=1e-8, msg="param %d" % i)
         sa, sb = oa.state[p], ob.state[q]

@@ -8,6 +8,11 @@
 //   m = m + (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // The gradients of all tables live in one flat buffer (gbase + goff[t]); the step counters are the
 // device-resident fp32 scalars torch keeps per parameter (already incremented by the caller).
+//
+// Optional L2 term (deepctr/models/basemodel.py:412-428, l2 * sum(w^2) added to the loss): with l2[t] given, the
+// kernel adds its gradient 2 l2[t] w to g on the fly (w is being read anyway) and returns the term's VALUE of
+// the pre-update weights (per-block partials summed in a fixed order by adam_l2_finish_kernel).  That removes
+// two table-sized passes per step (sum of squares; gradient initialisation) from the train step.
 #include "xdfm_internal.h"
 
 #define ADAM_THREADS 256
@@ -25,7 +30,8 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_tables_kernel(
     float* const* __restrict__ ps, float* const* __restrict__ ms, float* const* __restrict__ vs,
     const float* const* __restrict__ steps, const long* __restrict__ numel, const float* __restrict__ gbase,
-    const long* __restrict__ goff, double lr, double beta1, double beta2, double eps) {
+    const long* __restrict__ goff, double lr, double beta1, double beta2, double eps,
+    const float* __restrict__ l2, float* __restrict__ l2_part) {
     const int t = blockIdx.y;
     float* __restrict__ p = ps[t];
     float* __restrict__ m = ms[t];
@@ -37,6 +43,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_tables_kernel(
     const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, step));
     const float step_size = (float)(lr / bc1);
     const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)lr, (float)eps};
+    const float l2c = l2 ? l2[t] : 0.f;
+    const float g2 = 2.f * l2c;                        // d(l2 * w^2)/dw = 2 l2 w
+    float sq = 0.f;
     const long tid = (long)blockIdx.x * ADAM_THREADS + threadIdx.x;
     const long stride = (long)ADAM_BX * ADAM_THREADS;
     const bool vec = ((((size_t)p) | ((size_t)m) | ((size_t)v) | ((size_t)g)) & 15) == 0;
@@ -49,6 +58,9 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_tables_kernel(
     for (; i + stride < n4; i += 2 * stride) {            // two float4 per array in flight
         float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
         float4 pb = p4[i + stride], gb = g4[i + stride], mb = m4[i + stride], vb = v4[i + stride];
+        sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w) + (pb.x * pb.x + pb.y * pb.y) + (pb.z * pb.z + pb.w * pb.w);
+        ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+        gb.x = fmaf(g2, pb.x, gb.x); gb.y = fmaf(g2, pb.y, gb.y); gb.z = fmaf(g2, pb.z, gb.z); gb.w = fmaf(g2, pb.w, gb.w);
         adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
         adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
         adam_one(pb.x, gb.x, mb.x, vb.x, step_size, bc2_sqrt, c); adam_one(pb.y, gb.y, mb.y, vb.y, step_size, bc2_sqrt, c);
@@ -58,24 +70,57 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_tables_kernel(
     }
     for (; i < n4; i += stride) {
         float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+        sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+        ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
         adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
         adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
         p4[i] = pa; m4[i] = ma; v4[i] = va;
     }
     for (long k = 4 * n4 + tid; k < n; k += stride) {
         float pa = p[k], ma = m[k], va = v[k];
-        adam_one(pa, g[k], ma, va, step_size, bc2_sqrt, c);
+        sq = fmaf(pa, pa, sq);
+        adam_one(pa, fmaf(g2, pa, g[k]), ma, va, step_size, bc2_sqrt, c);
         p[k] = pa; m[k] = ma; v[k] = va;
+    }
+    if (l2_part) {                                     // fixed-order block reduction of the squares
+        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        __shared__ float wsum[ADAM_THREADS / 64];
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) l2_part[(long)t * ADAM_BX + blockIdx.x] = l2c * ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
     }
 }
 
-extern "C" int xdfm_adam_tables(float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
-                                const float* const* steps, const long* numel, int T, const float* gbase,
-                                const long* goff, double lr, double beta1, double beta2, double eps, void* stream) {
+__global__ __launch_bounds__(256) void adam_l2_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float acc[256];
+    float v = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) v += part[k];
+    acc[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) acc[threadIdx.x] += acc[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = acc[0];
+}
+
+extern "C" {
+
+size_t xdfm_adam_tables_ws_elems(int T) { return T > 0 ? (size_t)T * ADAM_BX : 0; }
+
+int xdfm_adam_tables(float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                     const float* const* steps, const long* numel, int T, const float* gbase,
+                     const long* goff, double lr, double beta1, double beta2, double eps,
+                     const float* l2, float* l2_ws, float* l2_value, void* stream) {
     XDFM_REQUIRE(params && exp_avg && exp_avg_sq && steps && numel && gbase && goff, "adam_tables: null pointer");
     XDFM_REQUIRE(T > 0 && T <= 65535, "adam_tables: bad tensor count %d", T);
     XDFM_REQUIRE(lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "adam_tables: bad hyper-parameters");
-    hipLaunchKernelGGL(adam_tables_kernel, dim3(ADAM_BX, T), dim3(ADAM_THREADS), 0, (hipStream_t)stream, params, exp_avg,
-                       exp_avg_sq, steps, numel, gbase, goff, lr, beta1, beta2, eps);
+    XDFM_REQUIRE(!l2_value || (l2 && l2_ws), "adam_tables: l2_value needs l2 and l2_ws");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_tables_kernel, dim3(ADAM_BX, T), dim3(ADAM_THREADS), 0, st, params, exp_avg, exp_avg_sq, steps,
+                       numel, gbase, goff, lr, beta1, beta2, eps, l2, l2_value ? l2_ws : nullptr);
+    if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(256), 0, st, l2_ws, T * ADAM_BX, l2_value);
     return xdfm_check_launch("adam_tables");
 }
+
+}  // extern "C"

@@ -104,7 +104,7 @@ __global__ void cin_bwd_pack_kernel(const float* __restrict__ W, int H, int Hp, 
 template <int HS4, int JB>
 __global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
     const float* __restrict__ dOut, const float* xp, const float* x0, const float* __restrict__ Wz,
-    int H, int Hp, int m, long N, int IB, float* dxp, float* dx0) {
+    int H, int Hp, int m, long N, int IB, float* dxp, float* dx0, int flags) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -190,14 +190,20 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_x_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = iblk * 32 + frag_row(r, s);
-            if (i < Hp && nok) dxp[(long)i * N + n] += dxa[r];
+            if (i < Hp && nok) {
+                float* d = dxp + (long)i * N + n;
+                *d = (flags & XDFM_BWX_SET_DXP) ? dxa[r] : *d + dxa[r];
+            }
         }
     }
     // flush the wave's dx0 slice
     for (int idx = lane; idx < m * 32; idx += 64) {
         const int j = idx >> 5;
         const long nn = n0 + (idx & 31);
-        if (nn < N) dx0[(long)j * N + nn] += dx0s[idx];
+        if (nn < N) {
+            float* d = dx0 + (long)j * N + nn;
+            *d = (flags & XDFM_BWX_SET_DX0) ? dx0s[idx] : *d + dx0s[idx];
+        }
     }
 }
 
@@ -669,7 +675,7 @@ __global__ void cin_bwd_w_unpack_kernel(const float* __restrict__ dWt, int H, in
 // =============================================================================================
 template <int HS4>
 static int launch_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
-                        int m, long N, float* dxp, float* dx0, hipStream_t st) {
+                        int m, long N, float* dxp, float* dx0, int flags, hipStream_t st) {
     const int IB = ceil_div(Hp, 32);
     size_t lds = (size_t)4 * m * 32 * sizeof(float);
     if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds);
@@ -678,10 +684,10 @@ static int launch_bwd_x(const float* dOut, const float* xp, const float* x0, con
     // single dependent chain at config 2, so it stays off by default (A/B knob: dbg bit 5).
     if (HS4 <= 16 && HS4 >= 4 && m % 2 == 0 && (xdfm_opt(OPT_DBG) & 32))
         hipLaunchKernelGGL((cin_bwd_x_kernel<HS4, 2>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, Wz, H,
-                           Hp, m, N, IB, dxp, dx0);
+                           Hp, m, N, IB, dxp, dx0, flags);
     else
         hipLaunchKernelGGL((cin_bwd_x_kernel<HS4, 1>), dim3(ceil_div(N, 128)), dim3(256), lds, st, dOut, xp, x0, Wz, H,
-                           Hp, m, N, IB, dxp, dx0);
+                           Hp, m, N, IB, dxp, dx0, flags);
     return xdfm_check_launch("cin_level_bwd_x");
 }
 
@@ -762,18 +768,24 @@ int xdfm_cin_bwd_pack(const float* W, int H, int Hp, int m, float* Wz, void* str
 
 int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
                          int m, long N, float* dxp, float* dx0, void* stream) {
+    return xdfm_cin_level_bwd_x_ex(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, 0, stream);
+}
+
+int xdfm_cin_level_bwd_x_ex(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
+                            int m, long N, float* dxp, float* dx0, int flags, void* stream) {
     XDFM_REQUIRE(dOut && xp && x0 && Wz && dxp && dx0, "cin_level_bwd_x: null pointer");
+    XDFM_REQUIRE((flags & ~(XDFM_BWX_SET_DXP | XDFM_BWX_SET_DX0)) == 0, "cin_level_bwd_x: unknown flags 0x%x", flags);
     XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_x: bad shape H=%d (<=256) Hp=%d m=%d",
                  H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_bwx_usable(H, Hp, m)) return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
+    if (x3_bwx_usable(H, Hp, m)) return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
     switch (bwx_hs4(H)) {
-        case 1: return launch_bwd_x<1>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
-        case 2: return launch_bwd_x<2>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
-        case 4: return launch_bwd_x<4>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
-        case 8: return launch_bwd_x<8>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
-        case 16: return launch_bwd_x<16>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
-        default: return launch_bwd_x<32>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, st);
+        case 1: return launch_bwd_x<1>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
+        case 2: return launch_bwd_x<2>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
+        case 4: return launch_bwd_x<4>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
+        case 8: return launch_bwd_x<8>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
+        case 16: return launch_bwd_x<16>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
+        default: return launch_bwd_x<32>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
     }
 }
 

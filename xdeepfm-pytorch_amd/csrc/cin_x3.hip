@@ -403,7 +403,7 @@ __global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, i
 template <int HBT, int NW>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
     const float* __restrict__ dOut, const float* xp, const float* x0, const float* __restrict__ pack,
-    int H, int Hp, int m, long N, int IB, float* dxp, float* dx0) {
+    int H, int Hp, int m, long N, int IB, float* dxp, float* dx0, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HBS = HBT > 8 ? 8 : HBT;      // h-blocks per stage
     constexpr int SPT = HBT / HBS;              // stages per tile
@@ -507,13 +507,19 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = iblk * 32 + frag_row(r, hh);
-            if (i < Hp && nok) dxp[(long)i * N + n] += dxa[r] * inv;
+            if (i < Hp && nok) {
+                float* d = dxp + (long)i * N + n;
+                *d = (flags & XDFM_BWX_SET_DXP) ? dxa[r] * inv : *d + dxa[r] * inv;
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int idx = lane; idx < m * 32; idx += 64) {
         const long nn = n0 + (idx & 31);
-        if (nn < N) dx0[(long)(idx >> 5) * N + nn] += dx0s[idx];
+        if (nn < N) {
+            float* d = dx0 + (long)(idx >> 5) * N + nn;
+            *d = (flags & XDFM_BWX_SET_DX0) ? dx0s[idx] : *d + dx0s[idx];
+        }
     }
 }
 
@@ -534,7 +540,7 @@ int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
 
 template <int HBT>
 static int launch_bwx3(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m,
-                       long N, const X3BwxGeom& g, float* dxp, float* dx0, hipStream_t st) {
+                       long N, const X3BwxGeom& g, float* dxp, float* dx0, int flags, hipStream_t st) {
     constexpr int HBS = HBT > 8 ? 8 : HBT;
     constexpr int NWMAX = (HBS * 2) % 8 == 0 ? 8 : 4;
     const size_t lds8 = (size_t)3 * HBS * 2048 + (size_t)2 * NWMAX * m * 32 * sizeof(float);
@@ -542,21 +548,21 @@ static int launch_bwx3(const float* dOut, const float* xp, const float* x0, cons
     if (lds4 > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds4);
     if (NWMAX == 8 && xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64 && lds8 <= 160 * 1024)
         hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, NWMAX>), dim3(ceil_div(N, 32 * NWMAX)), dim3(64 * NWMAX), lds8, st, dOut, xp,
-                           x0, pack, H, Hp, m, N, g.IB, dxp, dx0);
+                           x0, pack, H, Hp, m, N, g.IB, dxp, dx0, flags);
     else
         hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, 4>), dim3(ceil_div(N, 128)), dim3(256), lds4, st, dOut, xp, x0, pack, H, Hp,
-                           m, N, g.IB, dxp, dx0);
+                           m, N, g.IB, dxp, dx0, flags);
     return xdfm_check_launch("cin_level_bwd_x (f16x3)");
 }
 
 int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
-                   float* dxp, float* dx0, hipStream_t st) {
+                   float* dxp, float* dx0, int flags, hipStream_t st) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: packed weights must be 16-byte aligned");
     switch (g.HBT) {
-        case 2: return launch_bwx3<2>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, st);
-        case 4: return launch_bwx3<4>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, st);
-        case 8: return launch_bwx3<8>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, st);
-        default: return launch_bwx3<16>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, st);
+        case 2: return launch_bwx3<2>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+        case 4: return launch_bwx3<4>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+        case 8: return launch_bwx3<8>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+        default: return launch_bwx3<16>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
     }
 }

@@ -87,7 +87,7 @@ bool x3_bwx_usable(int H, int Hp, int m);
 size_t x3_bwx_pack_elems(int H, int Hp, int m);
 int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
 int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
-                   float* dxp, float* dx0, hipStream_t st);
+                   float* dxp, float* dx0, int flags, hipStream_t st);
 
 // ---- dW geometry (cin_bwd.hip, cin_x3_bww.hip) ---------------------------------------------------
 #define BWW_NC 32         // columns per staged chunk

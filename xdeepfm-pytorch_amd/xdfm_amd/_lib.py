@@ -35,12 +35,14 @@ SIGNATURES = {
     "xdfm_cin_bwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "xdfm_cin_level_bwd_x": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
+    "xdfm_cin_level_bwd_x_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P, P, c_int, P]),
     "xdfm_cin_bwd_w_ws_elems": (c_size_t, [c_int, c_int, c_int, c_long]),
     "xdfm_cin_level_bwd_w": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
-    "xdfm_adam_tables": (c_int, [P, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_double, P]),
+    "xdfm_adam_tables_ws_elems": (c_size_t, [c_int]),
+    "xdfm_adam_tables": (c_int, [P, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_double, P, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
     "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
     "xdfm_l2_reg_fwd": (c_int, [P, P, P, c_int, P, P, P]),

@@ -227,6 +227,24 @@ class BaseModel(nn.Module):
                     l2_terms.append((p, float(l2)))
         return l2_terms, l1_total
 
+    def _table_l2_fusion(self):
+        """Per-table L2 strengths when the optimizer applies the tables' L2 term itself while it streams the
+        weights (xdfm_amd.optim.TableAdam, K7), else None.  Only the model's own train step uses this."""
+        from .optim import TableAdam
+        opt = getattr(self, "optim", None)
+        tables = self._gather_tables()
+        if not isinstance(opt, TableAdam) or tables is None or not opt.owns(tables):
+            return None
+        coeff = {id(t): 0.0 for t in tables}
+        for weight_list, l1, l2 in self.regularization_weight:
+            for w in weight_list:
+                p = w[1] if isinstance(w, tuple) else w
+                if id(p) in coeff:
+                    if l1 > 0:
+                        return None
+                    coeff[id(p)] += float(l2)
+        return tables, [coeff[id(t)] for t in tables]
+
     def _gather_tables(self):
         """The tensors the fused gather reads, in its order (None before the first forward)."""
         if self._plan is None or not getattr(self, "_fused_linear", False):
@@ -286,10 +304,19 @@ class BaseModel(nn.Module):
         else:
             loss = loss_func(y_pred, y.squeeze(), reduction='sum')
         dp = xdist.current()
+        fuse = self._table_l2_fusion()
+        if fuse is not None:
+            self.optim.arm_table_l2(*fuse)          # gradient and value of the tables' L2 term come from K7
         if dp is None:
-            reg_loss = self.get_regularization_loss(_defer_tables=True)
+            reg_loss = self.get_regularization_loss(_part="rest") if fuse else self.get_regularization_loss(_defer_tables=True)
             total_loss = loss + reg_loss + self.aux_loss
             total_loss.backward()
+        elif fuse is not None:
+            reg_d = self.get_regularization_loss(_part="rest")
+            loss.backward()
+            dp.reduce_dense_grads(self)
+            (reg_d + self.aux_loss).backward()
+            total_loss = loss.detach() + reg_d.detach() + self.aux_loss
         else:
             # Data-loss gradients are SUMMED over ranks (the loss is a sum over the global batch); the L2
             # term is identical on every replica and must be applied once.  Tables: their gradient is
@@ -302,6 +329,8 @@ class BaseModel(nn.Module):
             (reg_d + self.aux_loss).backward()
             total_loss = loss.detach() + reg_t.detach() + reg_d.detach() + self.aux_loss
         self.optim.step()
+        if fuse is not None and self.optim.table_l2_value is not None:
+            total_loss = total_loss.detach() + self.optim.table_l2_value
         # detached: a caller that keeps these alive must not keep the step's autograd graph (and with it the
         # parameters' AccumulateGrad nodes and their stream) alive into the next step
         return y_pred.detach(), loss.detach(), total_loss.detach()
@@ -328,7 +357,8 @@ class BaseModel(nn.Module):
             self._optim_capturable = on_gpu
             if on_gpu:
                 from .optim import TableAdam
-                return TableAdam(params)
+                self._gather_plan()
+                return TableAdam(params, tables=self._gather_tables())
             return torch.optim.Adam(params)
         table = {"sgd": lambda p: torch.optim.SGD(p, lr=0.01), "adam": adam,
                  "adagrad": torch.optim.Adagrad, "rmsprop": torch.optim.RMSprop}

@@ -267,7 +267,8 @@ class CINStack(torch.autograd.Function):
         dev = x0.device
         levels, fm = cin_geometry(m, layer_size, split_half)
         g = g.contiguous()
-        dx0 = torch.zeros((m, N), dtype=torch.float32, device=dev)
+        dx0 = torch.empty((m, N), dtype=torch.float32, device=dev)      # first dX launch stores, later ones add
+        dx0_set = False
         grads = [None] * (2 * L)
         dhid = None                                  # gradient w.r.t. this level's hidden rows
         for l in range(L - 1, -1, -1):
@@ -291,7 +292,7 @@ class CINStack(torch.autograd.Function):
             if ctx.needs_input_grad[8 + 2 * l]:
                 grads[2 * l + 1] = dbias
             # dX: H <= 256 rows of the contraction per launch
-            dxp = torch.zeros((Hp, N), dtype=torch.float32, device=dev)
+            dxp = torch.empty((Hp, N), dtype=torch.float32, device=dev)
             W2 = W.reshape(H, Hp * m)
             hstep = _lib.get_option("x3_bwx_rows") or 256          # rows of the contraction per launch (<= 256)
             for h0 in range(0, H, hstep):
@@ -300,9 +301,11 @@ class CINStack(torch.autograd.Function):
                 wc = W2[h0:h0 + hc].contiguous()
                 _lib.check(lib.xdfm_cin_bwd_pack(_ptr(wc), hc, Hp, m, _ptr(wz), _stream()), "cin_bwd_pack")
                 dOc = dOut[h0:h0 + hc]
-                _lib.check(_run("cin_level_bwd_x", 2.0 * hc * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_x(
-                    _ptr(dOc), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m, N, _ptr(dxp), _ptr(dx0), _stream())),
+                flags = (1 if h0 == 0 else 0) | (0 if dx0_set else 2)     # XDFM_BWX_SET_DXP | XDFM_BWX_SET_DX0
+                _lib.check(_run("cin_level_bwd_x", 2.0 * hc * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_x_ex(
+                    _ptr(dOc), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m, N, _ptr(dxp), _ptr(dx0), flags, _stream())),
                     "cin_level_bwd_x")
+                dx0_set = True
             if l == 0:
                 dx0 += dxp                               # x_prev of level 0 is x0 itself
             dhid = dxp
