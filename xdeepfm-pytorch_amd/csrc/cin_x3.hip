@@ -282,7 +282,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             for (int il = 0; il < 4; ++il) xv[il] = xn[il];
         }
     };
-    for (int blk = 0; blk < G.FB; ++blk) block_steps(blk, MP, std::true_type{});
+    const int dbg = act >> 8;                            // timing experiments only (xdfm option "dbg" bits 6, 7)
+    act &= 0xff;
+    for (int blk = 0; blk < ((dbg & 2) ? 1 : G.FB); ++blk) block_steps(blk, MP, std::true_type{});
     if (G.TS > 0) block_steps(G.FB, G.TS, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two look-ahead stages must land before LDS is released
 
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (mb * MT + mt) * 32 + frag_row(r, hh);
-            if (row < H && nok) {
+            if (row < H && nok && (!(dbg & 1) || acc[mt][r] == 12345.f)) {
                 float v = acc[mt][r] * iW * ip * i0 + bias[row];
                 if (act == XDFM_ACT_RELU) v = fmaxf(v, 0.f);
                 out[(long)row * N + n] = v;
@@ -337,6 +339,7 @@ static int launch_x3(const float* xp, const float* x0, const float* pack, const 
 int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
                  int act, float* out, hipStream_t st) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
+    act |= ((xdfm_opt(OPT_DBG) >> 6) & 3) << 8;
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd: packed weights must be 16-byte aligned");
 #define X3_CASE(MTV, MV) \
     if (g.MT == MTV && m == MV) return launch_x3<MTV, MV>(xp, x0, pack, bias, H, Hp, N, g, act, out, st);

@@ -29,30 +29,52 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
     const int DV = D / VEC;
     const long N = (long)B * D;
 
-    // phase 1: gather rows into the LDS tile (chunk = VEC floats of one row)
-    const int nchunks = nb * m * DV;
-    for (int idx = tid; idx < nchunks; idx += EMB_THREADS) {
-        const int q = idx % DV;
-        const int rj = idx / DV;                 // = bl*m + j
-        const int j = rj % m;
-        const int bl = rj / m;
-        const float fid = X[(long)(b0 + bl) * ldx + cols[j]];
-        long id = (long)fid;                     // truncation, as Tensor.long() (basemodel.py:369)
+    // phase 0: the nb*m ids of the block -> LDS (clamped; out-of-range ids raise the flag), one load per thread
+    long* ids = reinterpret_cast<long*>(smem + ((((size_t)EB * m * (D + 1)) + 1) & ~(size_t)1));   // [EB][m], 8-byte aligned
+    for (int rj = tid; rj < nb * m; rj += EMB_THREADS) {
+        const int j = rj % m, bl = rj / m;
+        long id = (long)X[(long)(b0 + bl) * ldx + cols[j]];          // truncation, as Tensor.long() (basemodel.py:369)
         const int V = vocab[j];
         if (id < 0 || id >= V) {
-            if (err_flag && q == 0) atomicOr(err_flag, 1);
+            if (err_flag) atomicOr(err_flag, 1);
             id = id < 0 ? 0 : V - 1;
         }
-        const float* src = tables[j] + id * D + q * VEC;
-        float* dst = tile + (size_t)rj * D + q * VEC;
-        if constexpr (VEC == 4) {
-            *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
-        } else if constexpr (VEC == 2) {
-            *reinterpret_cast<float2*>(dst) = *reinterpret_cast<const float2*>(src);
-        } else {
-            *dst = *src;
+        ids[rj] = id;
+        if (lin_tables) linv[rj] = lin_tables[j][id];
+    }
+    __syncthreads();
+    // phase 1: gather rows into the LDS tile (chunk = VEC floats of one row).  GB chunks per thread are loaded
+    // back to back before any of them is stored, so a block pays about one HBM round trip for all its rows
+    // instead of one per loop iteration (the gather is latency-, not bandwidth-bound at 22 MB per batch).
+    const int nchunks = nb * m * DV;
+    constexpr int GB = 8;
+    for (int base = 0; base < nchunks; base += GB * EMB_THREADS) {
+        float4 v[GB];
+        int at[GB];
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            const int idx = base + k * EMB_THREADS + tid;
+            const int cidx = idx < nchunks ? idx : nchunks - 1;
+            const int q = cidx % DV, rj = cidx / DV;
+            const float* src = tables[rj % m] + ids[rj] * D + q * VEC;
+            at[k] = idx < nchunks ? rj * D + q * VEC : -1;
+            if constexpr (VEC == 4) {
+                v[k] = *reinterpret_cast<const float4*>(src);
+            } else if constexpr (VEC == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(src);
+                v[k] = make_float4(t.x, t.y, 0.f, 0.f);
+            } else {
+                v[k] = make_float4(*src, 0.f, 0.f, 0.f);
+            }
         }
-        if (q == 0 && lin_tables) linv[rj] = lin_tables[j][id];
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+            if (at[k] < 0) continue;
+            float* dst = tile + at[k];
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(dst) = v[k];
+            else if constexpr (VEC == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[k].x, v[k].y);
+            else *dst = v[k].x;
+        }
     }
     __syncthreads();
 
@@ -144,8 +166,11 @@ int xdfm_embed_gather_fwd(const float* X, long ldx, int B, const float* const* t
     // examples per block: tile <= 32 KiB, at most 16, at least 1
     int EB = (int)(8192 / ((long)m * D));
     if (EB > 16) EB = 16;
+    if ((xdfm_opt(OPT_DBG) & 256) && EB > 4) EB = 4;      // A/B: more, smaller workgroups
+    if ((xdfm_opt(OPT_DBG) & 512) && EB > 8) EB = 8;
     if (EB < 1) EB = 1;
-    const size_t lds = ((size_t)EB * m * D + (size_t)EB * m) * sizeof(float);
+    // tile + linear values + ids (8 bytes each; the float part is kept even so that the ids are 8-byte aligned)
+    const size_t lds = ((size_t)EB * m * D + (size_t)EB * m) * sizeof(float) + (size_t)EB * m * sizeof(long) + 8;
     XDFM_REQUIRE(lds <= 160 * 1024, "embed_gather_fwd: m*D=%ld too large for one LDS tile", (long)m * D);
     XDFM_REQUIRE(EB <= EMB_THREADS, "embed_gather_fwd: internal");
     dim3 grid(ceil_div(B, EB));
