@@ -64,6 +64,20 @@ __device__ __forceinline__ void x3_split2(float z0, float z1, h2& hi, h2& lo) {
     lo = __builtin_convertvector(r, h2);
 }
 
+// hi / lo halves of the two products a0*b0, a1*b1: one v_pk_mul_f32 + v_cvt_pk_f16_f32 for hi, then
+// lo = rne16(a*b - hi) with the exact product inside one v_fma_mix_f32 per element (its third operand is the
+// fp16 half, read in place) -- 5 VALU instructions per pair.
+__device__ __forceinline__ void x3_split_prod2(float a0, float b0, float a1, float b1, h2& hi, h2& lo) {
+    const f2 z = (f2){a0, a1} * (f2){b0, b1};
+    hi = __builtin_convertvector(z, h2);
+    const unsigned hbits = __builtin_bit_cast(unsigned, hi);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(b0), "v"(hbits));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(b1), "v"(hbits));
+    const f2 r = {r0, r1};
+    lo = __builtin_convertvector(r, h2);
+}
+
 // ---------------------------------------------------------------------------------------------
 // |W| maximum: every block stores its partial maximum in header slot X3_HDR_PART + blockIdx.x (plain stores,
 // no zero-initialised cell and no atomics: nothing here depends on a memset node inside a captured graph);
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
         for (int t2 = 0; t2 < 4; ++t2) {
             const int q = 8 * s + 2 * t2, il = q / M, j = q - il * M;
             h2 hi, lo;
-            if (il < 4) x3_split2(xv[il] * x0r[j], xv[il] * x0r[j + 1], hi, lo);
+            if (il < 4) x3_split_prod2(xv[il], x0r[j], xv[il], x0r[j + 1], hi, lo);
             else { hi = h2{0, 0}; lo = h2{0, 0}; }
             bh[2 * t2] = hi.x; bh[2 * t2 + 1] = hi.y;
             bl[2 * t2] = lo.x; bl[2 * t2 + 1] = lo.y;
@@ -473,10 +487,16 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
             xpr[r] = xp[(long)(i < Hp ? i : Hp - 1) * N + nc] * ((i < Hp) ? nmask : 0.f);
             dxa[r] = 0.f;
         }
-        for (int j = 0; j < m; ++j) {
-            f32x16 acc;
+        // One tile = HBT h-blocks of 3 MFMAs into `acc`.  The tile BEFORE it (accumulator `pacc`, column j = pj)
+        // is consumed in the shadow of these MFMAs, 16 / HBT registers per h-block: the dZ tile leaves the
+        // accumulator as dxp[i] += dZ x0[pj] and dx0[pj] += sum_i dZ xp[i] while the matrix pipe keeps running.
+        // (A zero `pacc` makes the first tile of an i-block consume nothing.)
+        constexpr int RPH = 16 / HBT;
+        auto run_tile = [&](f32x16& acc, const f32x16& pacc, int pj) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float px0 = x0s[pj * 32 + c];
+            float psj = 0.f;
 #pragma unroll
             for (int st = 0; st < SPT; ++st) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FPW) : "memory");
@@ -492,20 +512,61 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[hb], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[hb], acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[hb], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = hb * RPH; r < (hb + 1) * RPH; ++r) {
+                        dxa[r] = fmaf(pacc[r], px0, dxa[r]);
+                        psj = fmaf(pacc[r], xpr[r], psj);
+                    }
                 }
                 wcur += STAGE;
                 const int t = so0; so0 = so1; so1 = so2; so2 = t;
             }
-            // acc[r] = dZ[(i = iblk*32 + frag_row(r, hh), j)][n] * sW * sD
-            const float x0j = x0s[j * 32 + c];
-            float sj = 0.f;
+            psj += __shfl_xor(psj, 32);
+            if (hh == 0) dx0s[pj * 32 + c] += psj * inv;
+        };
+        // acc[r] = dZ[(i = iblk*32 + frag_row(r, hh), j)][n] * sW * sD
+        if constexpr (HBT >= 16) {
+            // 128 VGPRs of dOut leave no room for a second accumulator: consume each tile right away
+            f32x16 acc, zero;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zero[r] = 0.f;
+            for (int j = 0; j < m; ++j) {
+                run_tile(acc, zero, 0);
+                const float px0 = x0s[j * 32 + c];
+                float psj = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    dxa[r] = fmaf(acc[r], px0, dxa[r]);
+                    psj = fmaf(acc[r], xpr[r], psj);
+                }
+                psj += __shfl_xor(psj, 32);
+                if (hh == 0) dx0s[j * 32 + c] += psj * inv;
+            }
+        } else {
+        f32x16 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accB[r] = 0.f;
+        int j = 0;
+        for (; j + 2 <= m; j += 2) {
+            run_tile(accA, accB, j > 0 ? j - 1 : 0);
+            run_tile(accB, accA, j);
+        }
+        if (j < m) {                                   // odd m: one more tile, then its own consumption below
+            run_tile(accA, accB, j - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[r] = accA[r];
+        }
+        {   // the last tile of the i-block (in accB, column m-1) has no successor to hide behind
+            const float px0 = x0s[(m - 1) * 32 + c];
+            float psj = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                dxa[r] = fmaf(acc[r], x0j, dxa[r]);
-                sj = fmaf(acc[r], xpr[r], sj);
+                dxa[r] = fmaf(accB[r], px0, dxa[r]);
+                psj = fmaf(accB[r], xpr[r], psj);
             }
-            sj += __shfl_xor(sj, 32);
-            if (hh == 0) dx0s[j * 32 + c] += sj * inv;
+            psj += __shfl_xor(psj, 32);
+            if (hh == 0) dx0s[(m - 1) * 32 + c] += psj * inv;
+        }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -119,10 +119,15 @@ __device__ __forceinline__ void x3w_dma16(const void* g, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
 }
 
-__device__ __forceinline__ void x3w_split2(float z0, float z1, h2& hi, h2& lo) {
-    const f2 z = {z0, z1};
+// hi / lo halves of the products a0*b0, a1*b1 (see x3_split_prod2 in cin_x3.hip): 5 VALU instructions per pair
+__device__ __forceinline__ void x3w_split_prod2(float a0, float b0, float a1, float b1, h2& hi, h2& lo) {
+    const f2 z = (f2){a0, a1} * (f2){b0, b1};
     hi = __builtin_convertvector(z, h2);
-    const f2 r = {z0 - (float)hi.x, z1 - (float)hi.y};
+    const unsigned hbits = __builtin_bit_cast(unsigned, hi);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(b0), "v"(hbits));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(b1), "v"(hbits));
+    const f2 r = {r0, r1};
     lo = __builtin_convertvector(r, h2);
 }
 
@@ -225,7 +230,8 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_x3_kernel(
 #pragma unroll
                 for (int t2 = 0; t2 < 4; ++t2) {
                     h2 hi, lo;
-                    x3w_split2(xv[2 * t2] * fz[jt] * zv[2 * t2], xv[2 * t2 + 1] * fz[jt] * zv[2 * t2 + 1], hi, lo);
+                    const f2 xs = (f2){xv[2 * t2], xv[2 * t2 + 1]} * (f2){fz[jt], fz[jt]};     // row scales: exact
+                    x3w_split_prod2(xs.x, zv[2 * t2], xs.y, zv[2 * t2 + 1], hi, lo);
                     bh[jt][2 * t2] = hi.x; bh[jt][2 * t2 + 1] = hi.y;
                     bl[jt][2 * t2] = lo.x; bl[jt][2 * t2 + 1] = lo.y;
                 }
