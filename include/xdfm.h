@@ -194,20 +194,27 @@ int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* co
 size_t xdfm_colsum_ws_elems(int cols);
 int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* out, void* stream);
 
-/* ------------------------------------------------------------------ Adam over the tables (K7)
- * replaces: torch.optim.Adam.step() (deepctr/models/basemodel.py:452) for the embedding / linear tables, whose
- * gradients are dense (deepctr/inputs.py:168): one streaming launch, arithmetic of ATen's fused Adam in fp32.
- * params / exp_avg / exp_avg_sq: device arrays of T tensor base pointers; steps: device array of T pointers to
- * the fp32 step counters (already incremented for this step); numel: device long[T];
- * gradient of tensor t = gbase + goff[t] (device long[T], the layout xdfm_embed_scatter_bwd fills).
- * l2 (device float[T] or NULL): L2 strengths; the kernel then uses g + 2 l2[t] w as the gradient (the term
- * l2[t] * sum(w^2) of basemodel.py:412-428 with unit upstream gradient), and with l2_value != NULL also returns
- * sum_t l2[t] * sum(w_t^2) of the weights BEFORE the update (l2_ws: xdfm_adam_tables_ws_elems(T) floats). */
-size_t xdfm_adam_tables_ws_elems(int T);
-int xdfm_adam_tables(float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
-                     const float* const* steps, const long* numel, int T, const float* gbase, const long* goff,
-                     double lr, double beta1, double beta2, double eps,
-                     const float* l2, float* l2_ws, float* l2_value, void* stream);
+/* ------------------------------------------------------------------ Adam (K7)
+ * replaces: torch.optim.Adam.step() (deepctr/models/basemodel.py:452).  The embedding / linear tables carry
+ * dense gradients (deepctr/inputs.py:168), so the step streams every parameter: 28 B per parameter, arithmetic
+ * of ATen's fused Adam in fp32.  `tensors` is a HOST array of T descriptors (device pointers inside; they travel
+ * by value in the kernel arguments, 40 per launch); `step` points to the fp32 step counter torch keeps per
+ * parameter, already incremented for this step.
+ * l2 > 0 in a descriptor: the kernel uses g + 2*l2*w as the gradient (the term l2 * sum(w^2) of
+ * basemodel.py:412-428 with unit upstream gradient); with l2_value != NULL it also returns
+ * sum_t l2_t * sum(w_t^2) of the weights BEFORE the update (l2_ws: xdfm_adam_step_ws_elems(T) floats). */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    const float* step;
+    long numel;
+    float l2;
+} xdfm_adam_tensor;
+size_t xdfm_adam_step_ws_elems(int T);
+int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double beta1, double beta2, double eps,
+                   float* l2_ws, float* l2_value, void* stream);
 
 #ifdef __cplusplus
 }

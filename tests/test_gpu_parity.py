@@ -600,9 +600,10 @@ def test_graph_replay_of_train_step_matches_eager_launches():
 
 
 def test_table_adam_kernel_matches_torch_adam():
-    """K7 (xdfm_adam_tables) behind xdfm_amd.optim.TableAdam against torch.optim.Adam(fused=True): same state
-    layout and, over 6 steps with fresh dense gradients, the same parameters / moments to fp32 rounding.  The
-    large tensors' gradients are views of one flat buffer, as the gather's backward produces them."""
+    """K7 (xdfm_adam_step) behind xdfm_amd.optim.TableAdam against torch.optim.Adam(fused=True): same state
+    layout and, over 6 steps with fresh dense gradients, the same parameters / moments to fp32 rounding, with
+    the armed L2 term equal to adding 2*l2*w to the gradients by hand.  Gradients are views of one flat buffer
+    at odd offsets, as the gather's backward produces them."""
     from xdfm_amd.optim import TableAdam
     dev = _dev()
     torch.manual_seed(3)
@@ -610,7 +611,7 @@ def test_table_adam_kernel_matches_torch_adam():
     init = [torch.randn(s, device=dev) * 0.05 for s in shapes]
     pa = [torch.nn.Parameter(t.clone()) for t in init]
     pb = [torch.nn.Parameter(t.clone()) for t in init]
-    oa = TableAdam(pa, lr=2e-3, tables=pa[:3])                                # K7 for the three "tables"
+    oa = TableAdam(pa, lr=2e-3)
     ob = torch.optim.Adam(pb, lr=2e-3, fused=True)
     l2 = [1e-3, 0.0, 5e-2]
     sizes = [p.numel() for p in pa]
@@ -623,16 +624,16 @@ def test_table_adam_kernel_matches_torch_adam():
             q.grad = flat[off:off + n].view(p.shape).clone()
             off += n
         if step % 2:                   # every other step with the L2 term armed: K7 adds 2*l2*w and returns the value
-            oa.arm_table_l2(pa[:3], l2)
+            oa.arm_l2(pa[:3], l2)
             want_value = sum(c * float((q.detach().double() ** 2).sum()) for q, c in zip(pb[:3], l2))
             for q, c in zip(pb[:3], l2):
                 q.grad.add_(q.detach(), alpha=2 * c)
         oa.step()
         ob.step()
         if step % 2:
-            assert abs(float(oa.table_l2_value) - want_value) <= 1e-5 * want_value
+            assert abs(float(oa.l2_value) - want_value) <= 1e-5 * want_value
         else:
-            assert oa.table_l2_value is None
+            assert oa.l2_value is None
     for i, (p, q) in enumerate(zip(pa, pb)):
         close(p, q.detach().cpu().numpy(), rtol=2e-6, atol=1e-8, msg="param %d" % i)
         sa, sb = oa.state[p], ob.state[q]

@@ -140,13 +140,19 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-__global__ void colsum_finish_kernel(const float* __restrict__ part, int cols, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// 64 columns per block, the CS_ROWBLK partials of a column summed by 4 threads in a fixed order
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int q = threadIdx.x >> 6;
     float s = 0.f;
+    if (c < cols) {
 #pragma unroll
-    for (int k = 0; k < CS_ROWBLK; ++k) s += part[(long)k * cols + c];
-    out[c] = s;
+        for (int k = 0; k < CS_ROWBLK / 4; ++k) s += part[(long)(q * (CS_ROWBLK / 4) + k) * cols + c];
+    }
+    __shared__ float red[4][64];
+    red[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < cols) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 extern "C" {
@@ -158,7 +164,7 @@ int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* 
     XDFM_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "colsum: bad shape rows=%ld cols=%d ld=%ld", rows, cols, ld);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 64), CS_ROWBLK), dim3(256), 0, st, g, rows, cols, ld, ws);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, ws, cols, out);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, st, ws, cols, out);
     return xdfm_check_launch("colsum");
 }
 

@@ -41,13 +41,19 @@ SIGNATURES = {
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
-    "xdfm_adam_tables_ws_elems": (c_size_t, [c_int]),
-    "xdfm_adam_tables": (c_int, [P, P, P, P, P, c_int, P, P, c_double, c_double, c_double, c_double, P, P, P, P]),
+    "xdfm_adam_step_ws_elems": (c_size_t, [c_int]),
+    "xdfm_adam_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
     "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
     "xdfm_l2_reg_fwd": (c_int, [P, P, P, c_int, P, P, P]),
     "xdfm_l2_reg_bwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
 }
+
+class AdamTensor(ctypes.Structure):
+    """xdfm_adam_tensor of include/xdfm.h"""
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
+                ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float)]
+
 
 ABI_VERSION = 1
 _lib = None

@@ -227,23 +227,25 @@ class BaseModel(nn.Module):
                     l2_terms.append((p, float(l2)))
         return l2_terms, l1_total
 
-    def _table_l2_fusion(self):
-        """Per-table L2 strengths when the optimizer applies the tables' L2 term itself while it streams the
+    def _l2_fusion(self):
+        """(tensors, strengths) of the whole L2 term when the optimizer applies it itself while it streams the
         weights (xdfm_amd.optim.TableAdam, K7), else None.  Only the model's own train step uses this."""
         from .optim import TableAdam
         opt = getattr(self, "optim", None)
-        tables = self._gather_tables()
-        if not isinstance(opt, TableAdam) or tables is None or not opt.owns(tables):
+        if not isinstance(opt, TableAdam):
             return None
-        coeff = {id(t): 0.0 for t in tables}
+        tensors, coeffs = [], []
         for weight_list, l1, l2 in self.regularization_weight:
             for w in weight_list:
                 p = w[1] if isinstance(w, tuple) else w
-                if id(p) in coeff:
-                    if l1 > 0:
-                        return None
-                    coeff[id(p)] += float(l2)
-        return tables, [coeff[id(t)] for t in tables]
+                if l1 > 0 or not p.is_cuda:
+                    return None
+                if l2 > 0:
+                    tensors.append(p)
+                    coeffs.append(float(l2))
+        if not opt.owns(tensors):
+            return None
+        return tensors, coeffs
 
     def _gather_tables(self):
         """The tensors the fused gather reads, in its order (None before the first forward)."""
@@ -304,19 +306,19 @@ class BaseModel(nn.Module):
         else:
             loss = loss_func(y_pred, y.squeeze(), reduction='sum')
         dp = xdist.current()
-        fuse = self._table_l2_fusion()
+        fuse = self._l2_fusion()
         if fuse is not None:
-            self.optim.arm_table_l2(*fuse)          # gradient and value of the tables' L2 term come from K7
-        if dp is None:
-            reg_loss = self.get_regularization_loss(_part="rest") if fuse else self.get_regularization_loss(_defer_tables=True)
+            # gradient and value of the L2 term come from K7 (added after the gradient all-reduce when row-parallel:
+            # the term is identical on every replica and must count once)
+            self.optim.arm_l2(*fuse)
+            total_loss = loss + self.aux_loss
+            total_loss.backward()
+            if dp is not None:
+                dp.reduce_dense_grads(self)
+        elif dp is None:
+            reg_loss = self.get_regularization_loss(_defer_tables=True)
             total_loss = loss + reg_loss + self.aux_loss
             total_loss.backward()
-        elif fuse is not None:
-            reg_d = self.get_regularization_loss(_part="rest")
-            loss.backward()
-            dp.reduce_dense_grads(self)
-            (reg_d + self.aux_loss).backward()
-            total_loss = loss.detach() + reg_d.detach() + self.aux_loss
         else:
             # Data-loss gradients are SUMMED over ranks (the loss is a sum over the global batch); the L2
             # term is identical on every replica and must be applied once.  Tables: their gradient is
@@ -329,8 +331,8 @@ class BaseModel(nn.Module):
             (reg_d + self.aux_loss).backward()
             total_loss = loss.detach() + reg_t.detach() + reg_d.detach() + self.aux_loss
         self.optim.step()
-        if fuse is not None and self.optim.table_l2_value is not None:
-            total_loss = total_loss.detach() + self.optim.table_l2_value
+        if fuse is not None and self.optim.l2_value is not None:
+            total_loss = total_loss.detach() + self.optim.l2_value
         # detached: a caller that keeps these alive must not keep the step's autograd graph (and with it the
         # parameters' AccumulateGrad nodes and their stream) alive into the next step
         return y_pred.detach(), loss.detach(), total_loss.detach()
@@ -357,8 +359,7 @@ class BaseModel(nn.Module):
             self._optim_capturable = on_gpu
             if on_gpu:
                 from .optim import TableAdam
-                self._gather_plan()
-                return TableAdam(params, tables=self._gather_tables())
+                return TableAdam(params)
             return torch.optim.Adam(params)
         table = {"sgd": lambda p: torch.optim.SGD(p, lr=0.01), "adam": adam,
                  "adagrad": torch.optim.Adagrad, "rmsprop": torch.optim.RMSprop}

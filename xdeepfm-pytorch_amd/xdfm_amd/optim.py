@@ -1,34 +1,38 @@
-"""torch.optim.Adam whose step sends the gather's tables (44 M of the 45 M parameters at BASELINE config 2)
-through one streaming launch of the library (K7, `xdfm_adam_tables`) and every other tensor through ATen's
-fused kernel.  State layout (`step`, `exp_avg`, `exp_avg_sq` per parameter, device-resident fp32 step counters)
-and hyper-parameters are torch's, so `state_dict()` / `load_state_dict()` and code that edits `param_groups`
-keep working; anything the kernel does not implement (amsgrad, weight decay, maximize, tensor learning rates)
-falls back to `torch.optim.Adam.step`.  The update rule is the one basemodel.py:452 selects (torch.optim.Adam
-with default arguments).
+"""torch.optim.Adam whose step is the library's streaming kernel (K7, `xdfm_adam_step`): one launch per 40
+tensors for every fp32 CUDA parameter -- at BASELINE config 2 the embedding / linear tables are 44 M of the 45 M
+parameters, ATen's multi-tensor kernel moves them at 3.2 TB/s, K7 at 5.7 TB/s, and the ~15 small tensors stop
+costing a 47 us latency-bound launch of their own.  State layout (`step`, `exp_avg`, `exp_avg_sq` per
+parameter, device-resident fp32 step counters) and hyper-parameters are torch's, so `state_dict()` /
+`load_state_dict()` and code that edits `param_groups` keep working; anything the kernel does not implement
+(amsgrad, weight decay, maximize, tensor learning rates, non-fp32 parameters) falls back to
+`torch.optim.Adam.step`.  The update rule is the one basemodel.py:452 selects (torch.optim.Adam, defaults).
 
-The model's own train step may *arm* the tables' L2 term for one step (`arm_table_l2`): K7 then adds 2*l2*w to
-the gradients while it streams the weights and returns the term's value (`table_l2_value`), which saves the two
-table-sized passes the regulariser would otherwise need (basemodel.py:412-428)."""
+The model's own train step may *arm* an L2 term for one step (`arm_l2`): K7 then adds 2*l2*w to the gradients
+while it streams the weights and returns the term's value (`l2_value`), which removes the regulariser's own
+passes over the parameters (basemodel.py:412-428) from the step."""
+import ctypes
+
 import torch
-from torch.optim.adam import adam as _functional_adam
 
 from . import _lib
 
 
 class TableAdam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, tables=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, lr=lr, betas=betas, eps=eps, fused=True, capturable=True)
-        self._table_ids = {id(t): k for k, t in enumerate(tables or [])}
-        self._cache = {}            # group index -> (key, device pointer tables)
-        self._armed = None          # per-table L2 strengths for the next step only
-        self.table_l2_value = None  # [1] device tensor: value of the armed L2 term at the last step
+        self._armed = None          # id(parameter) -> L2 strength, for the next step only
+        self._desc = {}             # group index -> (key, ctypes array of xdfm_adam_tensor)
+        self.l2_value = None        # [1] device tensor: value of the armed L2 term at the last step
 
     def owns(self, tensors):
-        return len(self._table_ids) > 0 and all(id(t) in self._table_ids for t in tensors)
+        mine = {id(p) for g in self.param_groups for p in g["params"]}
+        return all(id(t) in mine for t in tensors)
 
-    def arm_table_l2(self, tensors, coeffs):
+    def arm_l2(self, tensors, coeffs):
         """The next step() adds the gradient of sum_t coeffs[t] * sum(tensors[t]^2) itself and reports its value."""
-        self._armed = {id(t): float(c) for t, c in zip(tensors, coeffs)}
+        self._armed = {}
+        for t, c in zip(tensors, coeffs):
+            self._armed[id(t)] = self._armed.get(id(t), 0.0) + float(c)
 
     def _plain(self, group):
         return (not group["amsgrad"] and group["weight_decay"] == 0 and not group["maximize"] and
@@ -36,87 +40,63 @@ class TableAdam(torch.optim.Adam):
                 isinstance(group["lr"], float) and all(isinstance(b, float) for b in group["betas"]) and
                 getattr(self, "grad_scale", None) is None and getattr(self, "found_inf", None) is None)
 
-    @staticmethod
-    def _l2_by_hand(params, grads, armed):
-        """Fallback when the tables cannot take the streaming kernel: apply the armed term with ATen ops."""
+    def _l2_by_hand(self, armed):
+        """Fallback path: apply the armed term with ATen ops before torch's own step."""
         value = None
-        for p, g in zip(params, grads):
-            c = armed.get(id(p), 0.0)
-            if c:
-                g.add_(p.detach(), alpha=2.0 * c)
-                term = c * p.detach().square().sum()
-                value = term if value is None else value + term
-        return value
+        for group in self.param_groups:
+            for p in group["params"]:
+                c = armed.get(id(p), 0.0)
+                if c and p.grad is not None:
+                    p.grad.add_(p.detach(), alpha=2.0 * c)
+                    term = c * p.detach().square().sum()
+                    value = term if value is None else value + term
+        self.l2_value = None if value is None else value.reshape(1)
 
     @torch.no_grad()
     def step(self, closure=None):
         armed, self._armed = self._armed, None
-        self.table_l2_value = None
+        self.l2_value = None
         if closure is not None or not all(self._plain(g) for g in self.param_groups):
             if armed:
-                for group in self.param_groups:
-                    ps = [p for p in group["params"] if p.grad is not None]
-                    v = self._l2_by_hand(ps, [p.grad for p in ps], armed)
-                    if v is not None:
-                        self.table_l2_value = v.reshape(1) if self.table_l2_value is None else self.table_l2_value + v
+                self._l2_by_hand(armed)
             return super().step(closure)
         self._cuda_graph_capture_health_check()
         lib = _lib.load()
         for gi, group in enumerate(self.param_groups):
             params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps = [], [], [], [], [], []
             has_complex = self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)
-            beta1, beta2 = group["betas"]
-            big = [i for i, p in enumerate(params) if id(p) in self._table_ids]
-            ok = len(big) > 0 and not has_complex and all(
-                params[i].is_cuda and params[i].dtype == torch.float32 and grads[i].dtype == torch.float32 and
-                params[i].is_contiguous() and grads[i].is_contiguous() for i in big)
-            # the gradients must be views of ONE buffer (the gather's flat table gradients): their offsets from the
-            # buffer start are then the same every step and the device tables are uploaded once
-            ok = ok and len({grads[i].untyped_storage().data_ptr() for i in big}) == 1
+            if not params:
+                continue
+            ok = not has_complex and all(
+                p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous() and
+                g.is_contiguous() and g.device == p.device for p, g in zip(params, grads))
             if not ok:
-                big = []
-            if big:
-                base = min(grads[i].data_ptr() for i in big)
-                l2 = tuple(armed.get(id(params[i]), 0.0) for i in big) if armed else None
-                key = (tuple(params[i].data_ptr() for i in big), tuple(exp_avgs[i].data_ptr() for i in big),
-                       tuple(grads[i].data_ptr() - base for i in big), l2)
-                tab = self._cache.get(gi)
-                if tab is None or tab[0] != key:
-                    dev = params[big[0]].device
-                    i64 = dict(dtype=torch.int64, device=dev)
-                    tab = (key, torch.tensor(key[0], **i64), torch.tensor(key[1], **i64),
-                           torch.tensor([exp_avg_sqs[i].data_ptr() for i in big], **i64),
-                           torch.tensor([steps[i].data_ptr() for i in big], **i64),
-                           torch.tensor([params[i].numel() for i in big], **i64),
-                           torch.tensor([o // 4 for o in key[2]], **i64),
-                           torch.tensor(l2, dtype=torch.float32, device=dev) if l2 is not None else None)
-                    self._cache[gi] = tab
-                torch._foreach_add_([steps[i] for i in big], 1)
-                _, p_t, m_t, v_t, s_t, n_t, o_t, l2_t = tab
-                dev = p_t.device
-                ws = val = None
-                if l2_t is not None:
-                    ws = torch.empty(lib.xdfm_adam_tables_ws_elems(len(big)), dtype=torch.float32, device=dev)
-                    val = torch.empty(1, dtype=torch.float32, device=dev)
-                stream = torch.cuda.current_stream(dev).cuda_stream
-                _lib.check(lib.xdfm_adam_tables(
-                    p_t.data_ptr(), m_t.data_ptr(), v_t.data_ptr(), s_t.data_ptr(), n_t.data_ptr(), len(big), base,
-                    o_t.data_ptr(), float(group["lr"]), float(beta1), float(beta2), float(group["eps"]),
-                    l2_t.data_ptr() if l2_t is not None else None, ws.data_ptr() if ws is not None else None,
-                    val.data_ptr() if val is not None else None, stream), "adam_tables")
-                if val is not None:
-                    self.table_l2_value = val if self.table_l2_value is None else self.table_l2_value + val
-            bigset = set(big)
-            small = [i for i in range(len(params)) if i not in bigset]
-            if small:
-                if armed:
-                    v = self._l2_by_hand([params[i] for i in small], [grads[i] for i in small], armed)
-                    if v is not None:
-                        self.table_l2_value = v.reshape(1) if self.table_l2_value is None else self.table_l2_value + v
-                _functional_adam([params[i] for i in small], [grads[i] for i in small], [exp_avgs[i] for i in small],
-                                 [exp_avg_sqs[i] for i in small], [], [steps[i] for i in small],
-                                 amsgrad=False, has_complex=has_complex, beta1=beta1, beta2=beta2, lr=group["lr"],
-                                 weight_decay=0, eps=group["eps"], maximize=False, foreach=group["foreach"],
-                                 capturable=True, differentiable=False, fused=True, grad_scale=None, found_inf=None,
-                                 decoupled_weight_decay=False)
+                raise RuntimeError("xdfm TableAdam: parameters and gradients must be contiguous fp32 CUDA tensors")
+            beta1, beta2 = group["betas"]
+            T = len(params)
+            l2 = tuple(armed.get(id(p), 0.0) for p in params) if armed else None
+            key = (tuple(p.data_ptr() for p in params), tuple(m.data_ptr() for m in exp_avgs), l2)
+            hit = self._desc.get(gi)
+            if hit is None or hit[0] != key:
+                arr = (_lib.AdamTensor * T)()
+                for k in range(T):
+                    arr[k].param, arr[k].exp_avg, arr[k].exp_avg_sq = params[k].data_ptr(), exp_avgs[k].data_ptr(), exp_avg_sqs[k].data_ptr()
+                    arr[k].step, arr[k].numel = steps[k].data_ptr(), params[k].numel()
+                    arr[k].l2 = l2[k] if l2 is not None else 0.0
+                hit = self._desc[gi] = (key, arr)
+            arr = hit[1]
+            for k in range(T):
+                arr[k].grad = grads[k].data_ptr()
+            torch._foreach_add_(steps, 1)
+            dev = params[0].device
+            ws = val = None
+            if l2 is not None and any(l2):
+                ws = torch.empty(lib.xdfm_adam_step_ws_elems(T), dtype=torch.float32, device=dev)
+                val = torch.empty(1, dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.xdfm_adam_step(ctypes.cast(arr, ctypes.c_void_p), T, float(group["lr"]), float(beta1),
+                                          float(beta2), float(group["eps"]), ws.data_ptr() if ws is not None else None,
+                                          val.data_ptr() if val is not None else None, stream), "adam_step")
+            if val is not None:
+                self.l2_value = val if self.l2_value is None else self.l2_value + val
         return None
