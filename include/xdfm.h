@@ -187,6 +187,20 @@ int xdfm_l2_reg_fwd(const float* const* ptrs, const long* numel, const float* co
 int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* coeff, int T,
                     const float* gscale, float* gflat, const long* goff, int accumulate, void* stream);
 
+/* ------------------------------------------------------------------ all weight packs of a step
+ * The packs depend on the weights only: with the f16x3 arithmetic one call prepares the forward pack and
+ * the dX pack of every level in two launches (max|W| of all levels, then all packs) instead of two per pack.
+ * jobs: HOST array; fwd_pack / bwd_pack sized by xdfm_cin_fwd_pack_elems / xdfm_cin_bwd_pack_elems (either may
+ * be NULL); every level must satisfy xdfm_cin_pack_all_supported (f16x3 kernels both ways, H <= 256). */
+typedef struct {
+    const float* W;
+    int H, Hp, m;
+    float* fwd_pack;
+    float* bwd_pack;
+} xdfm_cin_pack_job;
+int xdfm_cin_pack_all_supported(int H, int Hp, int m);
+int xdfm_cin_pack_all(const xdfm_cin_pack_job* jobs, int L, void* stream);
+
 /* ------------------------------------------------------------------ dense-layer bias gradient
  * replaces: autograd of deepctr/layers/core.py:120-134 w.r.t. the bias, grad_bias[c] = sum_r g[r][c].
  * Atomics-free and without any memset (safe inside a captured HIP graph), fixed summation order.

@@ -433,6 +433,22 @@ int xdfm_cin_fwd_pack(const float* W, int H, int Hp, int m, float* Wf, void* str
     }
 }
 
+int xdfm_cin_pack_all_supported(int H, int Hp, int m) {
+    return (H > 0 && Hp > 0 && m > 0 && x3_pack_all_usable(H, Hp, m)) ? 1 : 0;
+}
+
+int xdfm_cin_pack_all(const xdfm_cin_pack_job* jobs, int L, void* stream) {
+    XDFM_REQUIRE(jobs && L > 0 && L <= 8, "cin_pack_all: 1..8 jobs");
+    for (int l = 0; l < L; ++l) {
+        XDFM_REQUIRE(jobs[l].W && (jobs[l].fwd_pack || jobs[l].bwd_pack), "cin_pack_all: job %d has no weight / output", l);
+        XDFM_REQUIRE(xdfm_cin_pack_all_supported(jobs[l].H, jobs[l].Hp, jobs[l].m),
+                     "cin_pack_all: level %d (H=%d Hp=%d m=%d) has no f16x3 kernels in both directions", l, jobs[l].H,
+                     jobs[l].Hp, jobs[l].m);
+        XDFM_REQUIRE(((((size_t)jobs[l].fwd_pack) | ((size_t)jobs[l].bwd_pack)) & 15) == 0, "cin_pack_all: packs must be 16-byte aligned");
+    }
+    return x3_pack_all(jobs, L, (hipStream_t)stream);
+}
+
 int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const float* bias, int H, int Hp,
                        int m, long N, int act, float* out, void* stream) {
     XDFM_REQUIRE(xp && x0 && Wf && bias && out, "cin_level_fwd: null pointer");

@@ -126,11 +126,8 @@ __device__ __forceinline__ float x3_weight_scale(const float* __restrict__ hdr, 
 //   [mb][g < NS+2][mt < MT][p: 0 = hi, 1 = lo][lane][8 halves]   -- 1 KB per (mt, p) fragment
 // element t of lane (r = lane & 31, hh = lane >> 5) of step g = (blk, s):
 //   row = (mb*MT + mt)*32 + r,  q = 8s + t,  il = q / m,  j = q % m,  i = blk*8 + hh*RH + il
-__global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3Geom G, int nparts,
-                                   float* __restrict__ pack) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)G.MB * (G.NS + 2) * G.MT * 64;
-    if (idx >= total) return;
+__device__ __forceinline__ void x3_fwd_pack_one(const float* __restrict__ W, int H, int Hp, int m, const X3Geom& G,
+                                                int nparts, float* __restrict__ pack, long idx) {
     const float sW = x3_weight_scale(pack, nparts);
     if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
     const int lane = (int)(idx & 63);
@@ -157,6 +154,12 @@ __global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, i
     h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (((long)mb * (G.NS + 2) + g) * G.MT + mt) * 128 + lane;
     dst[0] = hi;
     dst[64] = lo;
+}
+
+__global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3Geom G, int nparts,
+                                   float* __restrict__ pack) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)G.MB * (G.NS + 2) * G.MT * 64) x3_fwd_pack_one(W, H, Hp, m, G, nparts, pack, idx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -388,10 +391,8 @@ bool x3_bwx_usable(int H, int Hp, int m) {
 
 // pack: [tile = iblk*m + j][hb < HBT][p][lane][8 halves]; element t of lane (r, hh):
 //   W[h = 16*hb + 8*hh + t][(iblk*32 + r)*m + j] * sW   (0 outside); two dummy stages appended.
-__global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3BwxGeom G, long total,
-                                   int nparts, float* __restrict__ pack) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
+__device__ __forceinline__ void x3_bwx_pack_one(const float* __restrict__ W, int H, int Hp, int m, const X3BwxGeom& G,
+                                                int nparts, float* __restrict__ pack, long idx) {
     const float sW = x3_weight_scale(pack, nparts);
     if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
     const int lane = (int)(idx & 63);
@@ -415,6 +416,67 @@ __global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, i
     h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (tile * G.HBT + hb) * 128 + lane;
     dst[0] = hi;
     dst[64] = lo;
+}
+
+__global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3BwxGeom G, long total,
+                                   int nparts, float* __restrict__ pack) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) x3_bwx_pack_one(W, H, Hp, m, G, nparts, pack, idx);
+}
+
+// ---- all levels, both directions, in two launches (the packs depend on the weights only) ----------------------
+#define X3_MAXJOBS 8
+struct X3PackJobs {
+    const float* W[X3_MAXJOBS];
+    float* fwd[X3_MAXJOBS];
+    float* bwd[X3_MAXJOBS];
+    int H[X3_MAXJOBS], Hp[X3_MAXJOBS], m[X3_MAXJOBS], nparts[X3_MAXJOBS];
+    long nW[X3_MAXJOBS], fthreads[X3_MAXJOBS], bthreads[X3_MAXJOBS];
+    X3Geom fg[X3_MAXJOBS];
+    X3BwxGeom bg[X3_MAXJOBS];
+};
+
+__global__ __launch_bounds__(1024) void x3_absmax_multi_kernel(const X3PackJobs J) {
+    const int l = blockIdx.y;
+    if ((int)blockIdx.x >= J.nparts[l]) return;
+    __shared__ float red[16];
+    const float* __restrict__ W = J.W[l];
+    const long total = J.nW[l], nv = total >> 2;
+    const long stride = (long)J.nparts[l] * blockDim.x;
+    float v = 0.f;
+    const bool vec = (((size_t)W) & 15) == 0;
+    if (vec) {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+            const float4 a = reinterpret_cast<const float4*>(W)[i];
+            v = fmaxf(fmaxf(v, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+        }
+    }
+    for (long i = (vec ? nv * 4 : 0) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) v = fmaxf(v, fabsf(W[i]));
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        v = red[threadIdx.x];
+        for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+        if (threadIdx.x == 0) {
+            if (J.fwd[l]) J.fwd[l][X3_HDR_PART + blockIdx.x] = v;
+            if (J.bwd[l]) J.bwd[l][X3_HDR_PART + blockIdx.x] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void x3_pack_multi_kernel(const X3PackJobs J) {
+    const int l = blockIdx.y >> 1, dir = blockIdx.y & 1;
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (dir == 0) {
+        if (!J.fwd[l]) return;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.fthreads[l]; idx += stride)
+            x3_fwd_pack_one(J.W[l], J.H[l], J.Hp[l], J.m[l], J.fg[l], J.nparts[l], J.fwd[l], idx);
+    } else {
+        if (!J.bwd[l]) return;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.bthreads[l]; idx += stride)
+            x3_bwx_pack_one(J.W[l], J.H[l], J.Hp[l], J.m[l], J.bg[l], J.nparts[l], J.bwd[l], idx);
+    }
 }
 
 template <int HBT, int NW>
@@ -629,4 +691,34 @@ int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const fl
         case 8: return launch_bwx3<8>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
         default: return launch_bwx3<16>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
     }
+}
+
+// every level through the f16x3 kernels in both directions?  (then xdfm_cin_pack_all can prepare a whole step)
+bool x3_pack_all_usable(int H, int Hp, int m) { return x3_fwd_usable(H, Hp, m) && x3_bwx_usable(H, Hp, m); }
+
+int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st) {
+    X3PackJobs J;
+    long maxthreads = 0;
+    int maxparts = 0;
+    for (int l = 0; l < X3_MAXJOBS; ++l) {
+        const xdfm_cin_pack_job& j = jobs[l < L ? l : 0];
+        J.W[l] = j.W; J.fwd[l] = l < L ? j.fwd_pack : nullptr; J.bwd[l] = l < L ? j.bwd_pack : nullptr;
+        J.H[l] = j.H; J.Hp[l] = j.Hp; J.m[l] = j.m;
+        J.nW[l] = (long)j.H * j.Hp * j.m;
+        J.nparts[l] = x3_absmax_blocks(J.nW[l]);
+        J.fg[l] = x3_fwd_geom(j.H, j.Hp, j.m);
+        J.bg[l] = x3_bwx_geom(j.H, j.Hp, j.m);
+        J.fthreads[l] = (long)J.fg[l].MB * (J.fg[l].NS + 2) * J.fg[l].MT * 64;
+        J.bthreads[l] = ((long)J.bg[l].NT * J.bg[l].HBT + 2 * J.bg[l].HBS) * 64;
+        if (l < L) {
+            if (J.fthreads[l] > maxthreads) maxthreads = J.fthreads[l];
+            if (J.bthreads[l] > maxthreads) maxthreads = J.bthreads[l];
+            if (J.nparts[l] > maxparts) maxparts = J.nparts[l];
+        }
+    }
+    hipLaunchKernelGGL(x3_absmax_multi_kernel, dim3(maxparts, L), dim3(1024), 0, st, J);
+    int gx = ceil_div(maxthreads, 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(x3_pack_multi_kernel, dim3(gx, 2 * L), dim3(256), 0, st, J);
+    return xdfm_check_launch("cin_pack_all");
 }

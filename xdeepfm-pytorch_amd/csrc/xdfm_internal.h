@@ -130,3 +130,6 @@ bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, l
 size_t x3_bww_ws_elems(int H, int Hp, int m, long N);
 int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
                    float* dW, hipStream_t st);
+
+bool x3_pack_all_usable(int H, int Hp, int m);
+int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st);

@@ -28,6 +28,8 @@ SIGNATURES = {
     "xdfm_embed_scatter_bwd": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P]),
     "xdfm_cin_fwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_fwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "xdfm_cin_pack_all_supported": (c_int, [c_int, c_int, c_int]),
+    "xdfm_cin_pack_all": (c_int, [P, c_int, P]),
     "xdfm_cin_level_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_int, P, P]),
     "xdfm_cin_direct_sum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_long, c_int, P]),
     "xdfm_cin_dout": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int,
@@ -48,6 +50,11 @@ SIGNATURES = {
     "xdfm_l2_reg_fwd": (c_int, [P, P, P, c_int, P, P, P]),
     "xdfm_l2_reg_bwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
 }
+
+class PackJob(ctypes.Structure):
+    """xdfm_cin_pack_job of include/xdfm.h"""
+    _fields_ = [("W", c_void_p), ("H", c_int), ("Hp", c_int), ("m", c_int), ("fwd_pack", c_void_p), ("bwd_pack", c_void_p)]
+
 
 class AdamTensor(ctypes.Structure):
     """xdfm_adam_tensor of include/xdfm.h"""

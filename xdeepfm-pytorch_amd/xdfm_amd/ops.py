@@ -235,12 +235,34 @@ class CINStack(torch.autograd.Function):
         outs: List[torch.Tensor] = []
         xp = x0
         result = torch.empty((B, fm), dtype=torch.float32, device=dev) if pool == "sum" else None
+        # The packed weights depend on the weights only.  When every level runs the f16x3 kernels both ways, all
+        # forward packs and (if a backward will follow) all dX packs are produced by two launches up front.
+        W2s = []
+        for l, (H, Hp, hid, dir0, drows, off) in enumerate(levels):
+            _need_cuda(params[2 * l], "cin weight")
+            W2s.append(params[2 * l].reshape(H, Hp * m).contiguous())
+        wfs, wzs = [None] * len(levels), None
+        if len(levels) <= 8 and all(lib.xdfm_cin_pack_all_supported(H, Hp, m) for (H, Hp, *_r) in levels):
+            need_bwd = any(ctx.needs_input_grad)
+            jobs = (_lib.PackJob * len(levels))()
+            wzs = [None] * len(levels)
+            for l, (H, Hp, *_r) in enumerate(levels):
+                wfs[l] = torch.empty(lib.xdfm_cin_fwd_pack_elems(H, Hp, m), dtype=torch.float32, device=dev)
+                if need_bwd:
+                    wzs[l] = torch.empty(lib.xdfm_cin_bwd_pack_elems(H, Hp, m), dtype=torch.float32, device=dev)
+                jobs[l].W, jobs[l].H, jobs[l].Hp, jobs[l].m = W2s[l].data_ptr(), H, Hp, m
+                jobs[l].fwd_pack = wfs[l].data_ptr()
+                jobs[l].bwd_pack = wzs[l].data_ptr() if need_bwd else None
+            _lib.check(lib.xdfm_cin_pack_all(ctypes.cast(jobs, ctypes.c_void_p), len(levels), _stream()), "cin_pack_all")
+            if not need_bwd:
+                wzs = None
         for l, (H, Hp, hid, dir0, drows, off) in enumerate(levels):
             W, bias = params[2 * l], params[2 * l + 1]
-            _need_cuda(W, "cin weight")
-            W2 = W.reshape(H, Hp * m).contiguous()
-            wf = torch.empty(lib.xdfm_cin_fwd_pack_elems(H, Hp, m), dtype=torch.float32, device=dev)
-            _lib.check(lib.xdfm_cin_fwd_pack(_ptr(W2), H, Hp, m, _ptr(wf), _stream()), "cin_fwd_pack")
+            W2 = W2s[l]
+            wf = wfs[l]
+            if wf is None:
+                wf = torch.empty(lib.xdfm_cin_fwd_pack_elems(H, Hp, m), dtype=torch.float32, device=dev)
+                _lib.check(lib.xdfm_cin_fwd_pack(_ptr(W2), H, Hp, m, _ptr(wf), _stream()), "cin_fwd_pack")
             A = torch.empty((H, N), dtype=torch.float32, device=dev)
             bias_c = bias.contiguous()
             _lib.check(_run("cin_level_fwd", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_fwd(
@@ -251,6 +273,8 @@ class CINStack(torch.autograd.Function):
             outs.append(A)
             xp = A[:hid] if hid > 0 else None
         ctx.cfg = (B, D, tuple(layer_size), split_half, act, pool, m)
+        ctx.wzs = wzs                                # dX packs made up front (or None), arithmetic mode they belong to
+        ctx.cin_math = _lib.get_option("cin_math")
         ctx.save_for_backward(x0, *outs, *params)
         if pool == "sum":
             return result
@@ -295,11 +319,16 @@ class CINStack(torch.autograd.Function):
             dxp = torch.empty((Hp, N), dtype=torch.float32, device=dev)
             W2 = W.reshape(H, Hp * m)
             hstep = _lib.get_option("x3_bwx_rows") or 256          # rows of the contraction per launch (<= 256)
+            prepacked = ctx.wzs is not None and ctx.wzs[l] is not None and hstep >= H and \
+                ctx.cin_math == _lib.get_option("cin_math")
             for h0 in range(0, H, hstep):
                 hc = min(hstep, H - h0)
-                wz = torch.empty(lib.xdfm_cin_bwd_pack_elems(hc, Hp, m), dtype=torch.float32, device=dev)
-                wc = W2[h0:h0 + hc].contiguous()
-                _lib.check(lib.xdfm_cin_bwd_pack(_ptr(wc), hc, Hp, m, _ptr(wz), _stream()), "cin_bwd_pack")
+                if prepacked:
+                    wz = ctx.wzs[l]
+                else:
+                    wz = torch.empty(lib.xdfm_cin_bwd_pack_elems(hc, Hp, m), dtype=torch.float32, device=dev)
+                    wc = W2[h0:h0 + hc].contiguous()
+                    _lib.check(lib.xdfm_cin_bwd_pack(_ptr(wc), hc, Hp, m, _ptr(wz), _stream()), "cin_bwd_pack")
                 dOc = dOut[h0:h0 + hc]
                 flags = (1 if h0 == 0 else 0) | (0 if dx0_set else 2)     # XDFM_BWX_SET_DXP | XDFM_BWX_SET_DX0
                 _lib.check(_run("cin_level_bwd_x", 2.0 * hc * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_x_ex(
