@@ -208,6 +208,17 @@ int xdfm_cin_pack_all(const xdfm_cin_pack_job* jobs, int L, void* stream);
 size_t xdfm_colsum_ws_elems(int cols);
 int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* out, void* stream);
 
+/* ------------------------------------------------------------------ output head of the binary task
+ * replaces: the logit sum of deepctr/models/xdeepfm.py:100-107, PredictionLayer (deepctr/layers/core.py:150-160:
+ * + bias, sigmoid) and F.binary_cross_entropy(reduction='sum') (basemodel.py:254) with their autograd -- about a
+ * dozen few-microsecond launches -- by one single-block launch each way.
+ * a, b, c: the logit parts [B] (b, c may be NULL); bias [1] or NULL; y [B] targets in [0,1];
+ * pred [B] out = sigmoid(a+b+c+bias); loss [1] out = sum BCE.  Backward: gloss [1] = d/d loss;
+ * dlogit [B] out (the gradient of every part); dbias [1] out or NULL. */
+int xdfm_head_fwd(const float* a, const float* b, const float* c, const float* bias, const float* y, int B, float* pred,
+                  float* loss, void* stream);
+int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, int B, float* dlogit, float* dbias, void* stream);
+
 /* ------------------------------------------------------------------ Adam (K7)
  * replaces: torch.optim.Adam.step() (deepctr/models/basemodel.py:452).  The embedding / linear tables carry
  * dense gradients (deepctr/inputs.py:168), so the step streams every parameter: 28 B per parameter, arithmetic

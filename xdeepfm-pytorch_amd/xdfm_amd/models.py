@@ -296,11 +296,31 @@ class BaseModel(nn.Module):
             step = self.__dict__["_graphed_step"] = GraphedStep(self)
         return step(x, y)
 
+    def _fused_head(self, x, y):
+        """(y_pred, loss) through one launch (ops.Head) when the model is the binary-task xDeepFM family with the
+        stock F.binary_cross_entropy loss; None otherwise."""
+        if self.loss_func is not F.binary_cross_entropy or not hasattr(self, "logit_parts") or not x.is_cuda:
+            return None
+        out = self.out
+        if getattr(out, "task", None) != "binary" or y.numel() != x.shape[0]:
+            return None
+        parts = self.logit_parts(x)
+        if len(parts) > 3 or any(p.numel() != x.shape[0] for p in parts):
+            return None
+        return ops.Head.apply(y, out.bias if out.use_bias else None, *parts)
+
     def _train_step_eager(self, x, y):
-        y_pred = self(x).squeeze()
         self.optim.zero_grad()
+        head = self._fused_head(x, y)
         loss_func = self.loss_func
-        if isinstance(loss_func, list):
+        if head is not None:
+            y_pred, loss = head
+            loss = loss.reshape(())
+        else:
+            y_pred = self(x).squeeze()
+        if head is not None:
+            pass
+        elif isinstance(loss_func, list):
             assert len(loss_func) == self.num_tasks, "the length of `loss_func` should be equal with `self.num_tasks`"
             loss = sum(loss_func[i](y_pred[:, i], y[:, i], reduction='sum') for i in range(self.num_tasks))
         else:
@@ -574,14 +594,22 @@ class _XDeepFMBase(BaseModel):
         self.cin_linear = nn.Linear(cin_out_dim, 1, bias=False).to(device)
         self.add_regularization_weight(filter(lambda x: 'weight' in x[0], self.cin.named_parameters()), l2=l2_reg_cin)
 
-    def forward(self, X):
+    def logit_parts(self, X):
+        """The summands of the logit, each [B, 1] (deepctr/models/xdeepfm.py:100-105): linear, CIN, DNN."""
         emb_fm, dnn_in, logit = self.fused_inputs(X)
+        parts = [logit]
         B = X.shape[0]
         if self.use_cin:
-            cin_out = self.cin.forward_fm(emb_fm, B, self._plan.D)
-            logit = logit + self.cin_linear(cin_out)
+            parts.append(self.cin_linear(self.cin.forward_fm(emb_fm, B, self._plan.D)))
         if self.use_dnn:
-            logit = logit + self.dnn_linear(self.dnn(dnn_in))
+            parts.append(self.dnn_linear(self.dnn(dnn_in)))
+        return parts
+
+    def forward(self, X):
+        parts = self.logit_parts(X)
+        logit = parts[0]
+        for p in parts[1:]:
+            logit = logit + p
         return self.out(logit)
 
 

@@ -469,6 +469,44 @@ def dense(x, W, b):
 
 
 # --------------------------------------------------------------------------------------------- #
+# output head                                                                                    #
+# --------------------------------------------------------------------------------------------- #
+class Head(torch.autograd.Function):
+    """(logit parts [B,1] ..., bias [1] or None, y [B,1]) -> (pred [B], loss [1]) with pred = sigmoid(sum parts +
+    bias) and loss = sum BCE(pred, y): deepctr/models/xdeepfm.py:100-107 + PredictionLayer (core.py:150-160) +
+    F.binary_cross_entropy(reduction='sum') (basemodel.py:254) in one launch each way.  `pred` is returned for
+    metrics and is not differentiable here (the model's train step differentiates the loss only)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, *parts):
+        lib = _lib.load()
+        parts = [p.reshape(-1).contiguous() for p in parts]
+        B = parts[0].numel()
+        yv = y.reshape(-1).contiguous()
+        pred = torch.empty(B, dtype=torch.float32, device=yv.device)
+        loss = torch.empty(1, dtype=torch.float32, device=yv.device)
+        a, b, c = (parts + [None, None])[:3]
+        _lib.check(lib.xdfm_head_fwd(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), _ptr(yv), B, _ptr(pred), _ptr(loss), _stream()),
+                   "head_fwd")
+        ctx.save_for_backward(pred, yv)
+        ctx.has_bias, ctx.shapes = bias is not None, None
+        ctx.mark_non_differentiable(pred)
+        return pred, loss
+
+    @staticmethod
+    def backward(ctx, _gpred, gloss):
+        lib = _lib.load()
+        pred, yv = ctx.saved_tensors
+        B = pred.numel()
+        dlogit = torch.empty((B, 1), dtype=torch.float32, device=pred.device)
+        dbias = torch.empty(1, dtype=torch.float32, device=pred.device) if ctx.has_bias else None
+        gl = gloss.reshape(1).contiguous()
+        _lib.check(lib.xdfm_head_bwd(_ptr(pred), _ptr(yv), _ptr(gl), B, _ptr(dlogit), _ptr(dbias), _stream()), "head_bwd")
+        n_parts = len(ctx.needs_input_grad) - 2
+        return (None, dbias) + tuple(dlogit if ctx.needs_input_grad[2 + k] else None for k in range(n_parts))
+
+
+# --------------------------------------------------------------------------------------------- #
 # L2 regulariser                                                                                 #
 # --------------------------------------------------------------------------------------------- #
 class L2Plan:
