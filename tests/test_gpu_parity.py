@@ -593,7 +593,7 @@ def test_graph_replay_of_train_step_matches_eager_launches():
     assert len(graphs) == 2                                   # lr 1e-3 and lr 3e-3, batch 256
     for e in graphs:
         n, n_memset, n_other = graphstep.census(e.graph)
-        assert n > 50 and n_memset == 0 and n_other == 0
+        assert n > 20 and n_memset == 0 and n_other == 0
     np.testing.assert_allclose(l_g, l_e, rtol=2e-5)
     for (k, a), (_, b) in zip(m_g.state_dict().items(), m_e.state_dict().items()):
         close(a, b.cpu().numpy(), rtol=2e-3, atol=2e-6, msg=k)

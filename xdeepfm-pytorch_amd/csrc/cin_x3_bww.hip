@@ -30,7 +30,7 @@ bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, l
            ((((size_t)dOut) | ((size_t)xp) | ((size_t)x0)) & 15) == 0;
 }
 
-#define X3_RM_COLS 16384      // columns per block of the row-maximum pass
+#define X3_RM_COLS 65536      // columns per block of the row-maximum pass
 struct X3BwwWs { long hdr, parts, planes, NP; int nbx; };     // element (float) counts of the workspace parts
 static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int H, int Hp, int m, long N) {
     X3BwwWs w;
@@ -48,10 +48,18 @@ static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int H, int Hp, int m, long N) 
 // dOut, [H, H+Hp) x_prev, [H+Hp, H+Hp+m) x0.  x3_rowscale_kernel reduces the partials to the power-of-two
 // scales hdr[0..Hpad) (dOut, < 2^15), hdr[Hpad..Hpad+IPAD) (x_prev, < 2^7), hdr[Hpad+IPAD..) (x0, < 2^7);
 // rows outside the matrices get scale 1.
+// hdr != NULL (only with gridDim.x == 1: one block covers a whole row): the block writes the row's scale itself
 __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict__ dOut, const float* __restrict__ xp,
                                                        const float* __restrict__ x0, int H, int Hp, long N,
-                                                       float* __restrict__ parts) {
-    const int row = blockIdx.y;
+                                                       float* __restrict__ parts, float* __restrict__ hdr, int Hpad,
+                                                       int IPAD) {
+    int row = blockIdx.y;
+    if (hdr) {                                          // blockIdx.y walks the header slots, padding included
+        const int t = blockIdx.y;
+        if (t < Hpad) { if (t >= H) { if (threadIdx.x == 0) hdr[t] = 1.f; return; } row = t; }
+        else if (t < Hpad + IPAD) { if (t - Hpad >= Hp) { if (threadIdx.x == 0) hdr[t] = 1.f; return; } row = H + (t - Hpad); }
+        else row = H + Hp + (t - Hpad - IPAD);
+    }
     const float* src = row < H ? dOut + (long)row * N : (row < H + Hp ? xp + (long)(row - H) * N : x0 + (long)(row - H - Hp) * N);
     float v = 0.f;
     const long base = (long)blockIdx.x * X3_RM_COLS;
@@ -67,7 +75,16 @@ __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict_
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) parts[(long)row * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (threadIdx.x == 0) {
+        const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (hdr) {
+            if (row < H) hdr[row] = x3w_pow2_scale(mx, 15);
+            else if (row < H + Hp) hdr[Hpad + (row - H)] = x3w_pow2_scale(mx, 7);
+            else hdr[Hpad + IPAD + (row - H - Hp)] = x3w_pow2_scale(mx, 7);
+        } else {
+            parts[(long)row * gridDim.x + blockIdx.x] = mx;
+        }
+    }
 }
 
 __global__ void x3_rowscale_kernel(const float* __restrict__ parts, int nbx, int H, int Hp, int m, int Hpad, int IPAD,
@@ -318,9 +335,15 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     float* parts = ws + w.hdr;
     char* planes = reinterpret_cast<char*>(ws + w.hdr + w.parts);
     float* slabs = ws + w.hdr + w.parts + w.planes;
-    hipLaunchKernelGGL(x3_rowmax_kernel, dim3(w.nbx, H + Hp + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, N, parts);
-    hipLaunchKernelGGL(x3_rowscale_kernel, dim3(ceil_div(g.Hpad + g.IPAD + m, 256)), dim3(256), 0, st, parts, w.nbx, H, Hp,
-                       m, g.Hpad, g.IPAD, hdr);
+    if (w.nbx == 1) {                   // one block covers a row: the maxima pass writes the scales itself
+        hipLaunchKernelGGL(x3_rowmax_kernel, dim3(1, g.Hpad + g.IPAD + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, N, parts,
+                           hdr, g.Hpad, g.IPAD);
+    } else {
+        hipLaunchKernelGGL(x3_rowmax_kernel, dim3(w.nbx, H + Hp + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, N, parts,
+                           (float*)nullptr, g.Hpad, g.IPAD);
+        hipLaunchKernelGGL(x3_rowscale_kernel, dim3(ceil_div(g.Hpad + g.IPAD + m, 256)), dim3(256), 0, st, parts, w.nbx, H,
+                           Hp, m, g.Hpad, g.IPAD, hdr);
+    }
     hipLaunchKernelGGL(x3_split_dout_kernel, dim3(ceil_div(w.NP, 2048), g.Hpad), dim3(256), 0, st, dOut, H, N, w.NP, hdr,
                        planes);
     int rc = xdfm_check_launch("cin_level_bwd_w split");

@@ -123,6 +123,7 @@ class BaseModel(nn.Module):
         self.gpus = gpus
         self.reg_loss = torch.zeros((1,), device=device)
         self.aux_loss = torch.zeros((1,), device=device)
+        self._aux_unset = True              # aux_loss is still the initial zero: the train step need not add it
         _reject_varlen(list(linear_feature_columns) + list(dnn_feature_columns))
         self.feature_index = build_input_features(list(linear_feature_columns) + list(dnn_feature_columns))
         self.embedding_dict = create_embedding_matrix(dnn_feature_columns, init_std, sparse=False, device=device)
@@ -331,7 +332,7 @@ class BaseModel(nn.Module):
             # gradient and value of the L2 term come from K7 (added after the gradient all-reduce when row-parallel:
             # the term is identical on every replica and must count once)
             self.optim.arm_l2(*fuse)
-            total_loss = loss + self.aux_loss
+            total_loss = loss if self._aux_unset else loss + self.aux_loss
             total_loss.backward()
             if dp is not None:
                 dp.reduce_dense_grads(self)
@@ -359,6 +360,7 @@ class BaseModel(nn.Module):
 
     def add_auxiliary_loss(self, aux_loss, alpha):
         self.aux_loss = aux_loss * alpha
+        self._aux_unset = False
 
     # ------------------------------------------------------------------ compile
     def compile(self, optimizer, loss=None, metrics=None):

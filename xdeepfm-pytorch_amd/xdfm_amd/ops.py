@@ -295,13 +295,15 @@ class CINStack(torch.autograd.Function):
         dx0_set = False
         grads = [None] * (2 * L)
         dhid = None                                  # gradient w.r.t. this level's hidden rows
+        dbias_all = torch.zeros(sum(lv[0] for lv in levels), dtype=torch.float32, device=dev)   # one fill for all levels
+        dbias_off = [sum(lv[0] for lv in levels[:k]) for k in range(L)]
         for l in range(L - 1, -1, -1):
             H, Hp, hid, dir0, drows, off = levels[l]
             A = outs[l]
             xp = x0 if l == 0 else outs[l - 1][:levels[l - 1][2]]
             W, bias = params[2 * l], params[2 * l + 1]
             dOut = torch.empty((H, N), dtype=torch.float32, device=dev)
-            dbias = torch.zeros((H,), dtype=torch.float32, device=dev)
+            dbias = dbias_all[dbias_off[l]:dbias_off[l] + H]
             has_hid = dhid is not None and hid > 0
             _lib.check(lib.xdfm_cin_dout(_ptr(A), H, B, D, act, _ptr(dhid) if has_hid else None, 0,
                                          hid if has_hid else 0, _ptr(g), 0 if pool == "sum" else 1,
