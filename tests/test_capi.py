@@ -63,8 +63,8 @@ def test_workspace_size_queries():
         assert lib.xdfm_cin_fwd_pack_elems(128, 128, 7) == 1 * (128 * 4 + 4) * 64 * 4             # odd m: fp32 kernel
         assert lib.xdfm_cin_bwd_pack_elems(128, 128, 26) == 128 + (4 * 26 * 8 + 2 * 8) * 512
         assert lib.xdfm_cin_bwd_pack_elems(300, 4, 4) == 0
-        # row scales + partial row maxima (one block per row here) + fp16 hi/lo planes of dOut + the slabs
-        assert lib.xdfm_cin_bwd_w_ws_elems(128, 64, 26, 65536) == 256 + 256 + 128 * 65536 + 26 * 128 * 64 * 71
+        # row scales + partial row maxima (4 blocks per row) + fp16 hi/lo planes of dOut + the slabs
+        assert lib.xdfm_cin_bwd_w_ws_elems(128, 64, 26, 65536) == 256 + 896 + 128 * 65536 + 26 * 128 * 64 * 71
     finally:
         _lib.set_option("cin_math", old)
 

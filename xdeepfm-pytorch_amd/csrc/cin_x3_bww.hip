@@ -30,7 +30,7 @@ bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, l
            ((((size_t)dOut) | ((size_t)xp) | ((size_t)x0)) & 15) == 0;
 }
 
-#define X3_RM_COLS 65536      // columns per block of the row-maximum pass
+#define X3_RM_COLS 16384      // columns per block of the row-maximum pass (one block per row was 2.5x slower at N = 65536)
 struct X3BwwWs { long hdr, parts, planes, NP; int nbx; };     // element (float) counts of the workspace parts
 static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int H, int Hp, int m, long N) {
     X3BwwWs w;
