@@ -208,16 +208,21 @@ int xdfm_cin_pack_all(const xdfm_cin_pack_job* jobs, int L, void* stream);
 size_t xdfm_colsum_ws_elems(int cols);
 int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* out, void* stream);
 
-/* ------------------------------------------------------------------ output head of the binary task
- * replaces: the logit sum of deepctr/models/xdeepfm.py:100-107, PredictionLayer (deepctr/layers/core.py:150-160:
- * + bias, sigmoid) and F.binary_cross_entropy(reduction='sum') (basemodel.py:254) with their autograd -- about a
- * dozen few-microsecond launches -- by one single-block launch each way.
- * a, b, c: the logit parts [B] (b, c may be NULL); bias [1] or NULL; y [B] targets in [0,1];
- * pred [B] out = sigmoid(a+b+c+bias); loss [1] out = sum BCE.  Backward: gloss [1] = d/d loss;
- * dlogit [B] out (the gradient of every part); dbias [1] out or NULL. */
-int xdfm_head_fwd(const float* a, const float* b, const float* c, const float* bias, const float* y, int B, float* pred,
-                  float* loss, void* stream);
-int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, int B, float* dlogit, float* dbias, void* stream);
+/* ------------------------------------------------------------------ output head of the binary task (K8)
+ * z_b = lin_b + <u_b, wu> + <v_b, wv> + bias,  pred = sigmoid(z),  loss = sum_b BCE(pred_b, y_b).
+ * replaces: cin_linear / dnn_linear (the two [B,K]x[K,1] products of deepctr/models/xdeepfm.py:95-105), the
+ * logit sum, PredictionLayer (deepctr/layers/core.py:150-160) and F.binary_cross_entropy(reduction='sum')
+ * (basemodel.py:254) with their autograd -- 2 GEMV + ~10 small launches forward, 4 skinny GEMMs + ~6 small
+ * launches backward -- by two launches each way; fixed summation order.
+ * lin [B] or NULL; u [B][Ku], wu [Ku] (or NULL); v [B][Kv], wv [Kv] (or NULL); bias [1] or NULL; y [B];
+ * ws: xdfm_head_ws_elems(Ku, Kv) floats.  Backward: gloss [1]; dlin [B] or NULL; du [B][Ku]; dv [B][Kv];
+ * grads [Ku + Kv + 1] = d wu | d wv | d bias. */
+size_t xdfm_head_ws_elems(int Ku, int Kv);
+int xdfm_head_fwd(const float* lin, const float* u, const float* wu, int Ku, const float* v, const float* wv, int Kv,
+                  const float* bias, const float* y, int B, float* pred, float* loss, float* ws, void* stream);
+int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, const float* u, const float* wu, int Ku,
+                  const float* v, const float* wv, int Kv, int B, float* dlin, float* du, float* dv, float* grads,
+                  float* ws, void* stream);
 
 /* ------------------------------------------------------------------ Adam (K7)
  * replaces: torch.optim.Adam.step() (deepctr/models/basemodel.py:452).  The embedding / linear tables carry

@@ -171,71 +171,132 @@ int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* 
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------
-// Output head of the binary task: p = sigmoid(a + b + c + bias), loss = sum_b BCE(p_b, y_b)
-// (deepctr/models/xdeepfm.py:100-107 logit sum, deepctr/layers/core.py:150-160 PredictionLayer,
-// basemodel.py:254 F.binary_cross_entropy(reduction='sum')) in one single-block launch each way instead of
-// ~12 elementwise / reduction launches of a few microseconds each.  BCE as ATen evaluates it: log terms
-// clamped at -100; backward (p - y) * p(1-p) / max(p(1-p), 1e-12).  Fixed summation order.
-__global__ __launch_bounds__(1024) void head_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                       const float* __restrict__ c, const float* __restrict__ bias,
-                                                       const float* __restrict__ y, int B, float* __restrict__ pred,
-                                                       float* __restrict__ loss) {
+// Output head of the binary task:  z_b = lin_b + <u_b, wu> + <v_b, wv> + bias,  p = sigmoid(z),  loss = sum_b BCE(p_b, y_b)
+// replaces cin_linear / dnn_linear (two [B,K]x[K,1] products, deepctr/models/xdeepfm.py:95-105), the logit sum,
+// PredictionLayer (deepctr/layers/core.py:150-160) and F.binary_cross_entropy(reduction='sum') (basemodel.py:254)
+// with their autograd -- two GEMV + ~10 elementwise / reduction launches forward and four skinny GEMMs + ~6
+// launches backward, each a few microseconds of launch floor -- by two launches each way.
+// BCE as ATen evaluates it: log terms clamped at -100; backward (p - y) * p(1-p) / max(p(1-p), 1e-12).
+// All sums in a fixed order (per-block partials + a finish kernel): deterministic.
+#define HEAD_BLOCKS 128
+#define HEAD_THREADS 256
+
+__device__ __forceinline__ float head_row_dot(const float* __restrict__ x, const float* __restrict__ w, int K, int lane) {
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(x[k], w[k], s);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
+// one wave per row (rows strided over all waves of the grid); per-block partial loss -> part[blockIdx.x]
+__global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(
+    const float* __restrict__ lin, const float* __restrict__ u, const float* __restrict__ wu, int Ku,
+    const float* __restrict__ v, const float* __restrict__ wv, int Kv, const float* __restrict__ bias,
+    const float* __restrict__ y, int B, float* __restrict__ pred, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float bv = bias ? bias[0] : 0.f;
-    float part = 0.f;
-    for (int i = threadIdx.x; i < B; i += 1024) {
-        float z = a[i];
-        if (b) z += b[i];
-        if (c) z += c[i];
-        z += bv;
+    float acc = 0.f;
+    for (int b = blockIdx.x * 4 + wave; b < B; b += HEAD_BLOCKS * 4) {
+        float z = (lin ? lin[b] : 0.f) + bv;
+        if (u) z += head_row_dot(u + (long)b * Ku, wu, Ku, lane);
+        if (v) z += head_row_dot(v + (long)b * Kv, wv, Kv, lane);
         const float p = 1.f / (1.f + expf(-z));
-        pred[i] = p;
-        const float t = y[i];
-        part += -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f));
+        const float t = y[b];
+        if (lane == 0) {
+            pred[b] = p;
+            acc += -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f));
+        }
     }
-    __shared__ float red[1024];
-    red[threadIdx.x] = part;
+    __shared__ float red[4];
+    if (lane == 0) red[wave] = acc;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(HEAD_BLOCKS) void head_fwd_finish_kernel(const float* __restrict__ part, float* __restrict__ loss) {
+    __shared__ float red[HEAD_BLOCKS];
+    red[threadIdx.x] = part[threadIdx.x];
+    __syncthreads();
+    for (int o = HEAD_BLOCKS / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
     if (threadIdx.x == 0) loss[0] = red[0];
 }
 
-__global__ __launch_bounds__(1024) void head_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ y,
-                                                       const float* __restrict__ gloss, int B, float* __restrict__ dlogit,
-                                                       float* __restrict__ dbias) {
+// g_b = gloss * dBCE/dz;  dlin_b = g_b;  du[b][k] = g_b wu[k];  dv likewise;
+// per-block partials of dwu[k] = sum_b g_b u[b][k], dwv[k], dbias = sum_b g_b  -> part[blk][Ku + Kv + 1]
+__global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(
+    const float* __restrict__ pred, const float* __restrict__ y, const float* __restrict__ gloss,
+    const float* __restrict__ u, const float* __restrict__ wu, int Ku, const float* __restrict__ v,
+    const float* __restrict__ wv, int Kv, int B, float* __restrict__ dlin, float* __restrict__ du,
+    float* __restrict__ dv, float* __restrict__ part) {
+    extern __shared__ float sm[];                 // [4 waves][Ku + Kv + 1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int KT = Ku + Kv + 1;
+    float* mine = sm + wave * KT;
+    for (int k = lane; k < KT; k += 64) mine[k] = 0.f;
     const float gl = gloss[0];
-    float part = 0.f;
-    for (int i = threadIdx.x; i < B; i += 1024) {
-        const float p = pred[i], t = y[i];
+    float gsum = 0.f;
+    for (int b = blockIdx.x * 4 + wave; b < B; b += HEAD_BLOCKS * 4) {
+        const float p = pred[b], t = y[b];
         const float pq = (1.f - p) * p;
         const float g = gl * (p - t) / fmaxf(pq, 1e-12f) * pq;
-        dlogit[i] = g;
-        part += g;
+        if (lane == 0 && dlin) dlin[b] = g;
+        gsum += g;
+        if (u) {
+            const float* ur = u + (long)b * Ku;
+            float* dr = du + (long)b * Ku;
+            for (int k = lane; k < Ku; k += 64) { dr[k] = g * wu[k]; mine[k] = fmaf(g, ur[k], mine[k]); }
+        }
+        if (v) {
+            const float* vr = v + (long)b * Kv;
+            float* dr = dv + (long)b * Kv;
+            for (int k = lane; k < Kv; k += 64) { dr[k] = g * wv[k]; mine[Ku + k] = fmaf(g, vr[k], mine[Ku + k]); }
+        }
     }
-    __shared__ float red[1024];
-    red[threadIdx.x] = part;
+    if (lane == 0) mine[Ku + Kv] = gsum;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0 && dbias) dbias[0] = red[0];
+    for (int k = threadIdx.x; k < KT; k += HEAD_THREADS)
+        part[(long)blockIdx.x * KT + k] = (sm[k] + sm[KT + k]) + (sm[2 * KT + k] + sm[3 * KT + k]);
+}
+
+__global__ void head_bwd_finish_kernel(const float* __restrict__ part, int KT, float* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= KT) return;
+    float s = 0.f;
+    for (int b = 0; b < HEAD_BLOCKS; ++b) s += part[(long)b * KT + k];
+    out[k] = s;
 }
 
 extern "C" {
 
-int xdfm_head_fwd(const float* a, const float* b, const float* c, const float* bias, const float* y, int B, float* pred,
-                  float* loss, void* stream) {
-    XDFM_REQUIRE(a && y && pred && loss && B > 0, "head_fwd: bad arguments");
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, b, c, bias, y, B, pred, loss);
+size_t xdfm_head_ws_elems(int Ku, int Kv) { return (size_t)HEAD_BLOCKS * (size_t)(Ku + Kv + 1) + HEAD_BLOCKS; }
+
+int xdfm_head_fwd(const float* lin, const float* u, const float* wu, int Ku, const float* v, const float* wv, int Kv,
+                  const float* bias, const float* y, int B, float* pred, float* loss, float* ws, void* stream) {
+    XDFM_REQUIRE(y && pred && loss && ws && B > 0, "head_fwd: bad arguments");
+    XDFM_REQUIRE((!u || (wu && Ku > 0)) && (!v || (wv && Kv > 0)) && Ku >= 0 && Kv >= 0, "head_fwd: bad operand shapes");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), 0, st, lin, u, wu, u ? Ku : 0, v, wv,
+                       v ? Kv : 0, bias, y, B, pred, ws);
+    hipLaunchKernelGGL(head_fwd_finish_kernel, dim3(1), dim3(HEAD_BLOCKS), 0, st, ws, loss);
     return xdfm_check_launch("head_fwd");
 }
 
-int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, int B, float* dlogit, float* dbias, void* stream) {
-    XDFM_REQUIRE(pred && y && gloss && dlogit && B > 0, "head_bwd: bad arguments");
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, y, gloss, B, dlogit, dbias);
+/* grads: [Ku + Kv + 1] = dwu | dwv | dbias */
+int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, const float* u, const float* wu, int Ku,
+                  const float* v, const float* wv, int Kv, int B, float* dlin, float* du, float* dv, float* grads,
+                  float* ws, void* stream) {
+    XDFM_REQUIRE(pred && y && gloss && grads && ws && B > 0, "head_bwd: bad arguments");
+    XDFM_REQUIRE((!u || (wu && du && Ku > 0)) && (!v || (wv && dv && Kv > 0)), "head_bwd: bad operand shapes");
+    const int ku = u ? Ku : 0, kv = v ? Kv : 0, KT = ku + kv + 1;
+    const size_t lds = (size_t)4 * KT * sizeof(float);
+    XDFM_REQUIRE(lds <= 64 * 1024, "head_bwd: Ku + Kv = %d too large", ku + kv);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), lds, st, pred, y, gloss, u, wu, ku, v, wv, kv,
+                       B, dlin, du, dv, ws);
+    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(ceil_div(KT, 256)), dim3(256), 0, st, ws, KT, grads);
     return xdfm_check_launch("head_bwd");
 }
 

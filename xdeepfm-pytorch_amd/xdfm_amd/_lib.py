@@ -43,8 +43,9 @@ SIGNATURES = {
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
     "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
-    "xdfm_head_fwd": (c_int, [P, P, P, P, P, c_int, P, P, P]),
-    "xdfm_head_bwd": (c_int, [P, P, P, c_int, P, P, P]),
+    "xdfm_head_ws_elems": (c_size_t, [c_int, c_int]),
+    "xdfm_head_fwd": (c_int, [P, P, P, c_int, P, P, c_int, P, P, c_int, P, P, P, P]),
+    "xdfm_head_bwd": (c_int, [P, P, P, P, P, c_int, P, P, c_int, c_int, P, P, P, P, P, P]),
     "xdfm_adam_step_ws_elems": (c_size_t, [c_int]),
     "xdfm_adam_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),

@@ -300,15 +300,15 @@ class BaseModel(nn.Module):
     def _fused_head(self, x, y):
         """(y_pred, loss) through one launch (ops.Head) when the model is the binary-task xDeepFM family with the
         stock F.binary_cross_entropy loss; None otherwise."""
-        if self.loss_func is not F.binary_cross_entropy or not hasattr(self, "logit_parts") or not x.is_cuda:
+        if self.loss_func is not F.binary_cross_entropy or not hasattr(self, "head_inputs") or not x.is_cuda:
             return None
         out = self.out
         if getattr(out, "task", None) != "binary" or y.numel() != x.shape[0]:
             return None
-        parts = self.logit_parts(x)
-        if len(parts) > 3 or any(p.numel() != x.shape[0] for p in parts):
-            return None
-        return ops.Head.apply(y, out.bias if out.use_bias else None, *parts)
+        lin, cin_out, dnn_out = self.head_inputs(x)
+        return ops.Head.apply(y, out.bias if out.use_bias else None, lin,
+                              cin_out, self.cin_linear.weight if cin_out is not None else None,
+                              dnn_out, self.dnn_linear.weight if dnn_out is not None else None)
 
     def _train_step_eager(self, x, y):
         self.optim.zero_grad()
@@ -596,22 +596,21 @@ class _XDeepFMBase(BaseModel):
         self.cin_linear = nn.Linear(cin_out_dim, 1, bias=False).to(device)
         self.add_regularization_weight(filter(lambda x: 'weight' in x[0], self.cin.named_parameters()), l2=l2_reg_cin)
 
-    def logit_parts(self, X):
-        """The summands of the logit, each [B, 1] (deepctr/models/xdeepfm.py:100-105): linear, CIN, DNN."""
+    def head_inputs(self, X):
+        """(linear logit [B,1], CIN output [B, featuremap_num] or None, DNN output [B, hidden] or None): what the
+        last stage (cin_linear, dnn_linear, sum, PredictionLayer; deepctr/models/xdeepfm.py:95-107) consumes."""
         emb_fm, dnn_in, logit = self.fused_inputs(X)
-        parts = [logit]
         B = X.shape[0]
-        if self.use_cin:
-            parts.append(self.cin_linear(self.cin.forward_fm(emb_fm, B, self._plan.D)))
-        if self.use_dnn:
-            parts.append(self.dnn_linear(self.dnn(dnn_in)))
-        return parts
+        cin_out = self.cin.forward_fm(emb_fm, B, self._plan.D) if self.use_cin else None
+        dnn_out = self.dnn(dnn_in) if self.use_dnn else None
+        return logit, cin_out, dnn_out
 
     def forward(self, X):
-        parts = self.logit_parts(X)
-        logit = parts[0]
-        for p in parts[1:]:
-            logit = logit + p
+        logit, cin_out, dnn_out = self.head_inputs(X)
+        if cin_out is not None:
+            logit = logit + self.cin_linear(cin_out)
+        if dnn_out is not None:
+            logit = logit + self.dnn_linear(dnn_out)
         return self.out(logit)
 
 

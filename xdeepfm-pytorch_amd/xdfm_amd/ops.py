@@ -474,38 +474,58 @@ def dense(x, W, b):
 # output head                                                                                    #
 # --------------------------------------------------------------------------------------------- #
 class Head(torch.autograd.Function):
-    """(logit parts [B,1] ..., bias [1] or None, y [B,1]) -> (pred [B], loss [1]) with pred = sigmoid(sum parts +
-    bias) and loss = sum BCE(pred, y): deepctr/models/xdeepfm.py:100-107 + PredictionLayer (core.py:150-160) +
-    F.binary_cross_entropy(reduction='sum') (basemodel.py:254) in one launch each way.  `pred` is returned for
-    metrics and is not differentiable here (the model's train step differentiates the loss only)."""
+    """(y [B,1], bias [1]|None, lin [B,1]|None, u [B,Ku]|None, wu [1,Ku]|None, v [B,Kv]|None, wv [1,Kv]|None) ->
+    (pred [B], loss [1]) with pred = sigmoid(lin + u wu^T + v wv^T + bias), loss = sum BCE(pred, y): cin_linear /
+    dnn_linear + logit sum (deepctr/models/xdeepfm.py:95-105) + PredictionLayer (core.py:150-160) +
+    F.binary_cross_entropy(reduction='sum') (basemodel.py:254), two launches each way (K8).  `pred` is returned
+    for metrics and is not differentiable here (the model's train step differentiates the loss only)."""
 
     @staticmethod
-    def forward(ctx, y, bias, *parts):
+    def forward(ctx, y, bias, lin, u, wu, v, wv):
         lib = _lib.load()
-        parts = [p.reshape(-1).contiguous() for p in parts]
-        B = parts[0].numel()
         yv = y.reshape(-1).contiguous()
-        pred = torch.empty(B, dtype=torch.float32, device=yv.device)
-        loss = torch.empty(1, dtype=torch.float32, device=yv.device)
-        a, b, c = (parts + [None, None])[:3]
-        _lib.check(lib.xdfm_head_fwd(_ptr(a), _ptr(b), _ptr(c), _ptr(bias), _ptr(yv), B, _ptr(pred), _ptr(loss), _stream()),
-                   "head_fwd")
-        ctx.save_for_backward(pred, yv)
-        ctx.has_bias, ctx.shapes = bias is not None, None
+        B = yv.numel()
+        dev = yv.device
+        linv = lin.reshape(-1).contiguous() if lin is not None else None
+        u = u.contiguous() if u is not None else None
+        v = v.contiguous() if v is not None else None
+        wu = wu.reshape(-1).contiguous() if wu is not None else None
+        wv = wv.reshape(-1).contiguous() if wv is not None else None
+        Ku = u.shape[1] if u is not None else 0
+        Kv = v.shape[1] if v is not None else 0
+        for t, k in ((u, Ku), (v, Kv)):
+            if t is not None and (t.dim() != 2 or t.shape[0] != B):
+                raise ValueError("xdfm head: operands must be [B, K]")
+        pred = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.xdfm_head_ws_elems(Ku, Kv), dtype=torch.float32, device=dev)
+        _lib.check(lib.xdfm_head_fwd(_ptr(linv), _ptr(u), _ptr(wu), Ku, _ptr(v), _ptr(wv), Kv, _ptr(bias), _ptr(yv), B,
+                                     _ptr(pred), _ptr(loss), _ptr(ws), _stream()), "head_fwd")
+        ctx.save_for_backward(pred, yv, u, wu, v, wv)
+        ctx.cfg = (bias is not None, lin is not None, tuple(lin.shape) if lin is not None else None, Ku, Kv)
         ctx.mark_non_differentiable(pred)
         return pred, loss
 
     @staticmethod
     def backward(ctx, _gpred, gloss):
         lib = _lib.load()
-        pred, yv = ctx.saved_tensors
+        pred, yv, u, wu, v, wv = ctx.saved_tensors
+        has_bias, has_lin, lin_shape, Ku, Kv = ctx.cfg
         B = pred.numel()
-        dlogit = torch.empty((B, 1), dtype=torch.float32, device=pred.device)
-        dbias = torch.empty(1, dtype=torch.float32, device=pred.device) if ctx.has_bias else None
+        dev = pred.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dlin = torch.empty(B, **f32) if has_lin else None
+        du = torch.empty((B, Ku), **f32) if u is not None else None
+        dv = torch.empty((B, Kv), **f32) if v is not None else None
+        grads = torch.empty(Ku + Kv + 1, **f32)
+        ws = torch.empty(lib.xdfm_head_ws_elems(Ku, Kv), **f32)
         gl = gloss.reshape(1).contiguous()
-        _lib.check(lib.xdfm_head_bwd(_ptr(pred), _ptr(yv), _ptr(gl), B, _ptr(dlogit), _ptr(dbias), _stream()), "head_bwd")
-        n_parts = len(ctx.needs_input_grad) - 2
-        return (None, dbias) + tuple(dlogit if ctx.needs_input_grad[2 + k] else None for k in range(n_parts))
+        _lib.check(lib.xdfm_head_bwd(_ptr(pred), _ptr(yv), _ptr(gl), _ptr(u), _ptr(wu), Ku, _ptr(v), _ptr(wv), Kv, B,
+                                     _ptr(dlin), _ptr(du), _ptr(dv), _ptr(grads), _ptr(ws), _stream()), "head_bwd")
+        return (None, grads[Ku + Kv:Ku + Kv + 1] if has_bias else None,
+                dlin.view(lin_shape) if has_lin else None,
+                du, grads[:Ku].view(1, Ku) if u is not None else None,
+                dv, grads[Ku:Ku + Kv].view(1, Kv) if v is not None else None)
 
 
 # --------------------------------------------------------------------------------------------- #
