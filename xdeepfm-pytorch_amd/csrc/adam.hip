@@ -41,10 +41,16 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     const float* __restrict__ g = d.grad;
     const long n = d.numel;
     const float* l2 = &d.l2;
-    const double step = (double)*d.step;
-    const double bc1 = 1.0 - pow(beta1, step);
-    const float bc2_sqrt = (float)sqrt(1.0 - pow(beta2, step));
-    const float step_size = (float)(lr / bc1);
+    // bias corrections in double as ATen does, once per block (two double pow() per THREAD cost more than
+    // the whole update of a small tensor)
+    __shared__ float bcs[2];
+    if (threadIdx.x == 0) {
+        const double step = (double)*d.step;
+        bcs[0] = (float)(lr / (1.0 - pow(beta1, step)));
+        bcs[1] = (float)sqrt(1.0 - pow(beta2, step));
+    }
+    __syncthreads();
+    const float step_size = bcs[0], bc2_sqrt = bcs[1];
     const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)lr, (float)eps};
     const float l2c = *l2;
     const float g2 = 2.f * l2c;                        // d(l2 * w^2)/dw = 2 l2 w
@@ -94,13 +100,13 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void adam_l2_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
-    __shared__ float acc[256];
+__global__ __launch_bounds__(1024) void adam_l2_finish_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+    __shared__ float acc[1024];
     float v = 0.f;
-    for (int k = threadIdx.x; k < n; k += 256) v += part[k];
+    for (int k = threadIdx.x; k < n; k += 1024) v += part[k];
     acc[threadIdx.x] = v;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if (threadIdx.x < o) acc[threadIdx.x] += acc[threadIdx.x + o];
         __syncthreads();
     }
@@ -129,7 +135,7 @@ int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double bet
         hipLaunchKernelGGL(adam_step_kernel, dim3(ADAM_BX, cnt), dim3(ADAM_THREADS), 0, st, batch, t0, lr, beta1, beta2, eps,
                            l2_value ? l2_ws : nullptr);
     }
-    if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(256), 0, st, l2_ws, T * ADAM_BX, l2_value);
+    if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(1024), 0, st, l2_ws, T * ADAM_BX, l2_value);
     return xdfm_check_launch("adam_step");
 }
 

@@ -188,7 +188,27 @@ __device__ __forceinline__ float head_row_dot(const float* __restrict__ x, const
     return s;
 }
 
-// one wave per row (rows strided over all waves of the grid); per-block partial loss -> part[blockIdx.x]
+// 16 lanes per row, 4 rows per wave at a time, float4 loads issued back to back (K % 4 == 0, 16-byte aligned rows)
+template <int MAXQ>
+__device__ __forceinline__ float head_row_dot_vec(const float* __restrict__ x, const float* __restrict__ w, int K4, int sub) {
+    float4 xv[MAXQ], wv[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int k = sub + 16 * q;
+        const int kc = k < K4 ? k : 0;
+        xv[q] = reinterpret_cast<const float4*>(x)[kc];
+        wv[q] = reinterpret_cast<const float4*>(w)[kc];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q)
+        if (sub + 16 * q < K4) s += (xv[q].x * wv[q].x + xv[q].y * wv[q].y) + (xv[q].z * wv[q].z + xv[q].w * wv[q].w);
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
+// rows strided over all 16-lane groups of the grid; per-block partial loss -> part[blockIdx.x]
+template <bool VEC>
 __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(
     const float* __restrict__ lin, const float* __restrict__ u, const float* __restrict__ wu, int Ku,
     const float* __restrict__ v, const float* __restrict__ wv, int Kv, const float* __restrict__ bias,
@@ -196,15 +216,32 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float bv = bias ? bias[0] : 0.f;
     float acc = 0.f;
-    for (int b = blockIdx.x * 4 + wave; b < B; b += HEAD_BLOCKS * 4) {
-        float z = (lin ? lin[b] : 0.f) + bv;
-        if (u) z += head_row_dot(u + (long)b * Ku, wu, Ku, lane);
-        if (v) z += head_row_dot(v + (long)b * Kv, wv, Kv, lane);
-        const float p = 1.f / (1.f + expf(-z));
-        const float t = y[b];
-        if (lane == 0) {
-            pred[b] = p;
-            acc += -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f));
+    if constexpr (VEC) {
+        const int sub = lane & 15, grp = lane >> 4;
+        for (int b = (blockIdx.x * 4 + wave) * 4 + grp; b < B; b += HEAD_BLOCKS * 16) {
+            float z = (lin ? lin[b] : 0.f) + bv;
+            if (u) z += head_row_dot_vec<8>(u + (long)b * Ku, wu, Ku >> 2, sub);       // K <= 512
+            if (v) z += head_row_dot_vec<8>(v + (long)b * Kv, wv, Kv >> 2, sub);
+            const float p = 1.f / (1.f + expf(-z));
+            const float t = y[b];
+            if (sub == 0) {
+                pred[b] = p;
+                acc += -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f));
+            }
+        }
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+    } else {
+        for (int b = blockIdx.x * 4 + wave; b < B; b += HEAD_BLOCKS * 4) {
+            float z = (lin ? lin[b] : 0.f) + bv;
+            if (u) z += head_row_dot(u + (long)b * Ku, wu, Ku, lane);
+            if (v) z += head_row_dot(v + (long)b * Kv, wv, Kv, lane);
+            const float p = 1.f / (1.f + expf(-z));
+            const float t = y[b];
+            if (lane == 0) {
+                pred[b] = p;
+                acc += -(t * fmaxf(logf(p), -100.f) + (1.f - t) * fmaxf(logf(1.f - p), -100.f));
+            }
         }
     }
     __shared__ float red[4];
@@ -278,8 +315,15 @@ int xdfm_head_fwd(const float* lin, const float* u, const float* wu, int Ku, con
     XDFM_REQUIRE(y && pred && loss && ws && B > 0, "head_fwd: bad arguments");
     XDFM_REQUIRE((!u || (wu && Ku > 0)) && (!v || (wv && Kv > 0)) && Ku >= 0 && Kv >= 0, "head_fwd: bad operand shapes");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), 0, st, lin, u, wu, u ? Ku : 0, v, wv,
-                       v ? Kv : 0, bias, y, B, pred, ws);
+    const int ku = u ? Ku : 0, kv = v ? Kv : 0;
+    const bool vec = ku % 4 == 0 && kv % 4 == 0 && ku <= 512 && kv <= 512 &&
+                     ((((size_t)u) | ((size_t)v) | ((size_t)wu) | ((size_t)wv)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(head_fwd_kernel<true>, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), 0, st, lin, u, wu, ku, v, wv, kv,
+                           bias, y, B, pred, ws);
+    else
+        hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), 0, st, lin, u, wu, ku, v, wv, kv,
+                           bias, y, B, pred, ws);
     hipLaunchKernelGGL(head_fwd_finish_kernel, dim3(1), dim3(HEAD_BLOCKS), 0, st, ws, loss);
     return xdfm_check_launch("head_fwd");
 }
