@@ -14,8 +14,9 @@ static int g_opts[OPT_COUNT] = {
     /* OPT_X3_FWD_MT */ 0,
     /* OPT_X3_BWX_ROWS */ 0,
     /* OPT_X3_WAVES */ 0,
+    /* OPT_BWW_PHASE */ 0,
 };
-static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math", "x3_fwd_mt", "x3_bwx_rows", "x3_waves"};
+static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math", "x3_fwd_mt", "x3_bwx_rows", "x3_waves", "bww_phase"};
 
 int xdfm_fail(int code, const char* fmt, ...) {
     va_list ap;

@@ -806,6 +806,8 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, in
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_w: bad shape H=%d Hp=%d m=%d", H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
     if (x3_bww_usable(dOut, xp, x0, H, N)) return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
+    const int phase = xdfm_opt(OPT_BWW_PHASE);            // fp32 kernels: the whole call counts as phase 2
+    if (phase == 1 || phase == 3) return XDFM_OK;
     switch (bww_mt(H)) {
         case 1: return launch_bwd_w<1>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
         case 2: return launch_bwd_w<2>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);

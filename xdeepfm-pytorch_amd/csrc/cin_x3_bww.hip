@@ -335,6 +335,11 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     float* parts = ws + w.hdr;
     char* planes = reinterpret_cast<char*>(ws + w.hdr + w.parts);
     float* slabs = ws + w.hdr + w.parts + w.planes;
+    // "bww_phase" lets a profiler bracket the MFMA kernel alone: the three phases of one call, run in order with
+    // the same arguments, are the whole call
+    const int phase = xdfm_opt(OPT_BWW_PHASE);
+    int rc = XDFM_OK;
+    if (phase == 0 || phase == 1) {
     if (w.nbx == 1) {                   // one block covers a row: the maxima pass writes the scales itself
         hipLaunchKernelGGL(x3_rowmax_kernel, dim3(1, g.Hpad + g.IPAD + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, N, parts,
                            hdr, g.Hpad, g.IPAD);
@@ -346,14 +351,20 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     }
     hipLaunchKernelGGL(x3_split_dout_kernel, dim3(ceil_div(w.NP, 2048), g.Hpad), dim3(256), 0, st, dOut, H, N, w.NP, hdr,
                        planes);
-    int rc = xdfm_check_launch("cin_level_bwd_w split");
+    rc = xdfm_check_launch("cin_level_bwd_w split");
     if (rc) return rc;
+    }
+    if (phase == 0 || phase == 2) {
     const size_t lds = (size_t)2 * (32 * 4 + 4 * (32 + 8)) * 128;
     hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4>), dim3(g.gx, g.nsplit), dim3(256), lds, st, planes, w.NP * 4, xp, x0, hdr, Hp,
                        m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab);
     rc = xdfm_check_launch("cin_level_bwd_w (f16x3)");
     if (rc) return rc;
+    }
+    if (phase == 0 || phase == 3) {
     hipLaunchKernelGGL(x3_bww_unpack_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, slabs, hdr, H, Hp, m, g.Hpad,
                        g.IPAD, g.nsplit, g.slab, dW);
-    return xdfm_check_launch("cin_level_bwd_w unpack (f16x3)");
+    rc = xdfm_check_launch("cin_level_bwd_w unpack (f16x3)");
+    }
+    return rc;
 }

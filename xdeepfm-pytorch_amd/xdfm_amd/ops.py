@@ -312,8 +312,22 @@ class CINStack(torch.autograd.Function):
             if ctx.needs_input_grad[7 + 2 * l]:
                 ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m, N), dtype=torch.float32, device=dev)
                 dW = torch.empty((H, Hp * m), dtype=torch.float32, device=dev)
-                _lib.check(_run("cin_level_bwd_w", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_w(
-                    _ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW), _stream())), "cin_level_bwd_w")
+                call = lambda: lib.xdfm_cin_level_bwd_w(_ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW),
+                                                        _stream())
+                if PROFILE is not None and _lib.get_option("cin_math") == 1:
+                    # per-kernel timing: run the call's three phases separately, events around the MFMA kernel only
+                    # (a shape without an f16x3 dW kernel ignores the knob: its whole call then runs once, in phase 2)
+                    try:
+                        _lib.set_option("bww_phase", 1)
+                        _lib.check(_run("cin_level_bwd_w passes", 0.0, call), "cin_level_bwd_w")
+                        _lib.set_option("bww_phase", 2)
+                        _lib.check(_run("cin_level_bwd_w", 2.0 * H * Hp * m * N, call), "cin_level_bwd_w")
+                        _lib.set_option("bww_phase", 3)
+                        _lib.check(_run("cin_level_bwd_w passes", 0.0, call), "cin_level_bwd_w")
+                    finally:
+                        _lib.set_option("bww_phase", 0)
+                else:
+                    _lib.check(_run("cin_level_bwd_w", 2.0 * H * Hp * m * N, call), "cin_level_bwd_w")
                 grads[2 * l] = dW.view(W.shape)
             if ctx.needs_input_grad[8 + 2 * l]:
                 grads[2 * l + 1] = dbias
