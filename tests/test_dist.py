@@ -63,47 +63,51 @@ def _make_model(device, oracle_backed):
     return model, names + dnames, orc
 
 
-def _data(orc):
-    X, y = orc.synthetic_batch(150, VOCAB, ND, seed=5)       # 150 rows: ragged last batch (150 = 2*64 + 22)
+def _data(orc, n_rows):
+    X, y = orc.synthetic_batch(n_rows, VOCAB, ND, seed=5)    # ragged last batch (150 = 2*64 + 22, 342 = 5*64 + 22)
     Xv, yv = orc.synthetic_batch(40, VOCAB, ND, seed=6)
     return X, y, Xv, yv
 
 
-def _run(device, oracle_backed, per_rank_bs):
+def _run(device, oracle_backed, per_rank_bs, n_rows=150):
     model, names, orc = _make_model(device, oracle_backed)
-    X, y, Xv, yv = _data(orc)
+    X, y, Xv, yv = _data(orc, n_rows)
     hist = model.fit({n: X[:, i] for i, n in enumerate(names)}, y, batch_size=per_rank_bs, epochs=2, verbose=2,
                      validation_data=({n: Xv[:, i] for i, n in enumerate(names)}, yv), shuffle=True)
     state = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    step = model.__dict__.get("_graphed_step")
+    state["__replays__"] = np.array([step.replays if step is not None else 0])
     return {k: list(v) for k, v in hist.history.items()}, state
 
 
-def _worker(rank, world, port, device, oracle_backed, out_dir):
+def _worker(rank, world, port, device, oracle_backed, out_dir, n_rows=150):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     import torch.distributed as dist
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        hist, state = _run(device, oracle_backed, per_rank_bs=32)
+        hist, state = _run(device, oracle_backed, per_rank_bs=32, n_rows=n_rows)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), hist_keys=np.array(sorted(hist)),
                  hist_vals=np.array([hist[k] for k in sorted(hist)]), **{"p:" + k: v for k, v in state.items()})
     finally:
         dist.destroy_process_group()
 
 
-def _check(tmp_path, device, oracle_backed, rtol, atol):
+def _check(tmp_path, device, oracle_backed, rtol, atol, n_rows=150):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, device, oracle_backed, str(tmp_path)), nprocs=2, join=True)
-    hist1, state1 = _run(device, oracle_backed, per_rank_bs=64)          # single process, global batch 64
+    mp.spawn(_worker, args=(2, port, device, oracle_backed, str(tmp_path), n_rows), nprocs=2, join=True)
+    hist1, state1 = _run(device, oracle_backed, per_rank_bs=64, n_rows=n_rows)   # single process, global batch 64
     r0 = np.load(str(tmp_path / "rank0.npz"))
     r1 = np.load(str(tmp_path / "rank1.npz"))
     keys = [str(k) for k in r0["hist_keys"]]
     assert keys == sorted(hist1)
     np.testing.assert_allclose(r0["hist_vals"], np.array([hist1[k] for k in keys]), rtol=rtol, atol=atol)
     np.testing.assert_allclose(r1["hist_vals"], r0["hist_vals"], rtol=1e-6, atol=1e-7)   # every rank logs the same
+    replays = (int(r0["p:__replays__"][0]), int(r1["p:__replays__"][0]), int(state1.pop("__replays__")[0]))
     for k, v in state1.items():
         np.testing.assert_allclose(r0["p:" + k], v, rtol=rtol, atol=atol, err_msg=k)
         np.testing.assert_allclose(r1["p:" + k], r0["p:" + k], rtol=0, atol=1e-7, err_msg="replicas differ: " + k)
+    return replays
 
 
 def test_split_points_cover_every_row_once():
@@ -123,4 +127,7 @@ def test_row_parallel_fit_equals_single_process_cpu_gloo(tmp_path):
 def test_row_parallel_fit_equals_single_process_gpu(tmp_path):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    _check(tmp_path, "cuda:0", False, rtol=1e-3, atol=2e-5)
+    # 342 rows = 5 full global batches + a ragged one per epoch: from the third full batch on, each rank replays the
+    # collective-free half of its step from a HIP graph and the single-process run replays its whole step
+    replays = _check(tmp_path, "cuda:0", False, rtol=1e-3, atol=2e-5, n_rows=342)
+    assert min(replays) >= 2, replays

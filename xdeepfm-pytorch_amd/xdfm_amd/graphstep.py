@@ -77,14 +77,26 @@ class GraphedStep(object):
 
     def eligible(self, x, y):
         m = self.model
-        return (not self.disabled and x.is_cuda and y.is_cuda and ops.PROFILE is None and xdist.current() is None and
-                getattr(m, "_optim_capturable", False) and torch.is_grad_enabled())
+        if self.disabled or not (x.is_cuda and y.is_cuda) or ops.PROFILE is not None or not torch.is_grad_enabled() \
+                or not getattr(m, "_optim_capturable", False):
+            return False
+        dp = xdist.current()
+        if dp is None:
+            return True
+        # row-parallel: only the collective-free first half of the split step is captured; it needs equal shards
+        # (static shapes on every rank) and the L2 term in the optimizer
+        if os.environ.get("XDFM_HIP_GRAPH_DP", "1") == "0" or not m._can_split_step(dp, m._l2_fusion()):
+            return False
+        n = dp._n_global
+        return n is not None and n % dp.world == 0 and x.shape[0] == n // dp.world
 
     def __call__(self, x, y):
         m = self.model
         if not self.eligible(x, y):
             return m._train_step_eager(x, y)
-        key = (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, x.device.index, self._signature())
+        dp = xdist.current()
+        key = (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, x.device.index, self._signature(),
+               None if dp is None else dp.world)
         ent = self.entries.get(key)
         if ent is None:
             if len(self.entries) >= MAX_GRAPHS:             # each graph owns the activations of one step
@@ -100,6 +112,9 @@ class GraphedStep(object):
         ent.sy.copy_(y)
         ent.graph.replay()
         self.replays += 1
+        if dp is not None:          # captured: the first half; exchange, scatter, all-reduce and optimizer follow eagerly
+            y_pred, loss, stash = ent.out
+            return m._split_step_second(y_pred, loss, stash, m._l2_fusion())
         return ent.out
 
     def _eager_on_side_stream(self, x, y):
@@ -129,7 +144,10 @@ class GraphedStep(object):
             if self.stream is None:
                 self.stream = torch.cuda.Stream(device=x.device)
             with torch.cuda.graph(g, stream=self.stream):
-                out = m._train_step_eager(ent.sx, ent.sy)
+                if xdist.current() is None:
+                    out = m._train_step_eager(ent.sx, ent.sy)
+                else:
+                    out = m._split_step_first(ent.sx, ent.sy)
             n, n_memset, n_other = census(g)
             if n_memset or n_other:
                 raise RuntimeError("captured train step holds %d memset and %d unexpected nodes of %d"

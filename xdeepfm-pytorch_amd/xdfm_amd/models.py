@@ -310,24 +310,63 @@ class BaseModel(nn.Module):
                               cin_out, self.cin_linear.weight if cin_out is not None else None,
                               dnn_out, self.dnn_linear.weight if dnn_out is not None else None)
 
-    def _train_step_eager(self, x, y):
-        self.optim.zero_grad()
+    def _loss_forward(self, x, y):
+        """(y_pred, data loss): forward + loss of the reference's batch loop (basemodel.py:250-254)."""
         head = self._fused_head(x, y)
-        loss_func = self.loss_func
         if head is not None:
             y_pred, loss = head
-            loss = loss.reshape(())
-        else:
-            y_pred = self(x).squeeze()
-        if head is not None:
-            pass
-        elif isinstance(loss_func, list):
+            return y_pred, loss.reshape(())
+        y_pred = self(x).squeeze()
+        loss_func = self.loss_func
+        if isinstance(loss_func, list):
             assert len(loss_func) == self.num_tasks, "the length of `loss_func` should be equal with `self.num_tasks`"
             loss = sum(loss_func[i](y_pred[:, i], y[:, i], reduction='sum') for i in range(self.num_tasks))
         else:
             loss = loss_func(y_pred, y.squeeze(), reduction='sum')
+        return y_pred, loss
+
+    # Row-parallel step with the L2 term in K7, in two halves.  The first (forward, loss, backward down to the
+    # row gradients of the gather) contains no collective, so it can be replayed from a HIP graph; the second
+    # exchanges the rows, scatters, all-reduces the dense gradients and runs the optimizer, eagerly.
+    def _split_step_first(self, x, y):
+        self.optim.zero_grad()
+        plan = self._gather_plan()
+        plan.stash = []
+        try:
+            y_pred, loss = self._loss_forward(x, y)
+            (loss if self._aux_unset else loss + self.aux_loss).backward()
+            stash = plan.stash
+        finally:
+            plan.stash = None
+        return y_pred.detach(), loss.detach(), stash
+
+    def _split_step_second(self, y_pred, loss, stash, fuse):
+        dp = xdist.current()
+        dense_w = self.linear_model.weight if getattr(self.linear_model, "dense_feature_columns", None) else None
+        ops.apply_stashed_scatter(stash, dense_w, self._gather_tables())
+        if dp is not None:
+            dp.reduce_dense_grads(self)
+        self.optim.arm_l2(*fuse)
+        self.optim.step()
+        total_loss = loss if self._aux_unset else loss + self.aux_loss.detach()
+        if self.optim.l2_value is not None:
+            total_loss = total_loss + self.optim.l2_value
+        return y_pred, loss, total_loss.detach()
+
+    def _can_split_step(self, dp, fuse):
+        if dp is None or fuse is None:
+            return False
+        self._gather_plan()
+        return bool(getattr(self, "_fused_linear", False))
+
+    def _train_step_eager(self, x, y):
         dp = xdist.current()
         fuse = self._l2_fusion()
+        if self._can_split_step(dp, fuse):
+            y_pred, loss, stash = self._split_step_first(x, y)
+            return self._split_step_second(y_pred, loss, stash, fuse)
+        self.optim.zero_grad()
+        y_pred, loss = self._loss_forward(x, y)
         if fuse is not None:
             # gradient and value of the L2 term come from K7 (added after the gradient all-reduce when row-parallel:
             # the term is identical on every replica and must count once)

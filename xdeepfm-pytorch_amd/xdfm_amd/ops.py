@@ -71,6 +71,7 @@ class EmbedPlan:
         self._off_cache = {}
         self.dp = None            # set by xdfm_amd.dist to exchange row gradients across ranks
         self.reg_defer = None     # (gscale, L2Plan) left by L2Reg.backward: table L2 gradient still owed
+        self.stash = None         # list: gather backwards park their inputs here instead of scattering (split step)
 
     def on(self, device):
         key = str(device)
@@ -153,11 +154,23 @@ class EmbedGather(torch.autograd.Function):
     def backward(ctx, d_emb, d_dnn, d_lin):
         X = ctx.saved_tensors[0]
         tables = ctx.saved_tensors[1:]
-        plan, has_lin = ctx.plan, ctx.has_lin
+        plan = ctx.plan
+        if plan.stash is not None:
+            # split step (row-parallel run replayed from a HIP graph): the scatter needs the other ranks' rows, so
+            # it runs after the exchange, outside the captured part -- see apply_stashed_scatter
+            plan.stash.append((plan, X, d_emb, d_dnn, d_lin, ctx.has_lin, ctx.shapes, tables, ctx.needs_input_grad[1]))
+            return (None, None, None, None) + (None,) * len(tables)
+        grads, d_w = EmbedGather.scatter(plan, X, d_emb, d_dnn, d_lin, ctx.has_lin, ctx.shapes, tables)
+        need_w = ctx.needs_input_grad[1]
+        return (None, d_w if (need_w and plan.nd) else None, None, None) + tuple(grads)
+
+    @staticmethod
+    def scatter(plan, X, d_emb, d_dnn, d_lin, has_lin, shapes, tables):
+        """Dense table gradients (views of one flat buffer) and the dense-weight gradient from the row gradients."""
         lib = _lib.load()
         m, D, nd = plan.m, plan.D, plan.nd
         dev = X.device
-        sizes, offs, total, off_dev = plan.grad_layout(ctx.shapes, dev)
+        sizes, offs, total, off_dev = plan.grad_layout(shapes, dev)
         # ONE buffer holds every dense table gradient (+ the dense-weight gradient at its end).  It
         # starts as zeros, or -- when L2Reg.backward deferred the tables' L2 term to us -- as
         # 2*l2*gscale*w, which saves a memset, a table-sized temporary and one add per table.
@@ -171,7 +184,7 @@ class EmbedGather(torch.autograd.Function):
                                            _ptr(flat), _ptr(off_dev), 0, _stream()), "l2_reg_bwd (deferred)")
         else:
             flat = torch.zeros(total + max(nd, 1), dtype=torch.float32, device=dev)
-        grads = [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, ctx.shapes)]
+        grads = [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
         d_w = flat[total:total + nd].view(nd, 1) if nd else None
         cols, vocab, dcols, _ = plan.on(dev)
         tab_off = off_dev[:m]
@@ -189,8 +202,21 @@ class EmbedGather(torch.autograd.Function):
                 _ptr(Xr), Xr.stride(0), B, _ptr(cols), _ptr(vocab), m, D, _ptr(dcols) if nd else None, nd,
                 _ptr(de), _ptr(dd), _ptr(dl), _ptr(flat), _ptr(tab_off), _ptr(lin_off), _ptr(d_w), _stream())),
                 "embed_scatter_bwd")
-        need_w = ctx.needs_input_grad[1]
-        return (None, d_w if (need_w and nd) else None, None, None) + tuple(grads)
+        return grads, d_w
+
+
+def apply_stashed_scatter(stash, dense_w, params=None):
+    """Second half of a split step: exchange + scatter for every stashed gather backward; the gradients are
+    assigned to `.grad` of the tables (`params`: the model's own parameter objects, in the gather's order) and of
+    `dense_w`, the linear part's dense weight, directly."""
+    with torch.no_grad():
+        for (plan, X, d_emb, d_dnn, d_lin, has_lin, shapes, tables, need_w) in stash:
+            grads, d_w = EmbedGather.scatter(plan, X, d_emb, d_dnn, d_lin, has_lin, shapes, tables)
+            owners = params if params is not None and len(params) == len(tables) else tables
+            for t, g in zip(owners, grads):
+                t.grad = g
+            if need_w and d_w is not None and dense_w is not None:
+                dense_w.grad = d_w.clone()
 
 
 # --------------------------------------------------------------------------------------------- #
