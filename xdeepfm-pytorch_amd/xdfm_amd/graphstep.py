@@ -143,10 +143,13 @@ class GraphedStep(object):
             g = torch.cuda.CUDAGraph(keep_graph=True)
             if self.stream is None:
                 self.stream = torch.cuda.Stream(device=x.device)
-            with torch.cuda.graph(g, stream=self.stream):
-                if xdist.current() is None:
+            if xdist.current() is None:
+                with torch.cuda.graph(g, stream=self.stream):
                     out = m._train_step_eager(ent.sx, ent.sy)
-                else:
+            else:
+                # thread_local: the process group's watchdog thread polls events while we capture; it must not be
+                # able to invalidate the capture (nothing it touches is part of it)
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
                     out = m._split_step_first(ent.sx, ent.sy)
             n, n_memset, n_other = census(g)
             if n_memset or n_other:
