@@ -149,8 +149,10 @@ __device__ __forceinline__ void x3w_split_prod2(float a0, float b0, float a1, fl
 }
 
 // wave tile as in cin_bwd_w_dma4_kernel: 32*MT rows of h x (32 i's of block iblk) x JT = 2 values of j
-template <int MT>
-__global__ __launch_bounds__(256, 2) void cin_bwd_w_x3_kernel(
+// NW waves per workgroup share the staged dOut chunk: with 8 waves the planes are streamed by half as many
+// workgroups and half as many n-splits (slabs) are needed to fill the chip with one resident round
+template <int MT, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
     const char* __restrict__ planes, long PB, const float* __restrict__ xp, const float* __restrict__ x0,
     const float* __restrict__ hdr, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
     int IPAD, float* __restrict__ dWt, long slab_stride) {
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_x3_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int wt0 = blockIdx.x * 4;
+    const int wt0 = blockIdx.x * NW;
     const int hg = wt0 / TPH;
     const int tin = wt0 + wave - hg * TPH;
     const bool active = tin < JP * IB;
@@ -172,12 +174,13 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_x3_kernel(
 
     constexpr int DROWS = 32 * MT;
     constexpr int WROWS = 32 + 8;                       // x_prev block + one 8-row group holding the x0 rows
-    constexpr int BUF = (DROWS + 4 * WROWS) * 128;      // bytes
-    constexpr int ND_D = DROWS / 32;
+    constexpr int BUF = (DROWS + NW * WROWS) * 128;     // bytes
+    constexpr int ND_D = DROWS / (8 * NW);              // dOut-plane DMA instructions per wave (8 rows each)
     constexpr int NDMA = ND_D + 4 + 1;
+    static_assert(DROWS % (8 * NW) == 0, "every wave stages the same number of dOut rows");
 
     const int lrow = lane >> 3, pc = lane & 7;
-    const int drow0 = wave * (DROWS / 4);
+    const int drow0 = wave * (DROWS / NW);
     auto swz = [](int row) { return (row >> 1) & 7; };
 
     auto dma_k = [&](int k, long nc0, int buf) {
@@ -320,15 +323,35 @@ __global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+static inline int x3_bww_waves() { return xdfm_opt(OPT_X3_WAVES) == 4 ? 4 : 8; }
+
+// tiling of bww_geometry with NW wave tiles per workgroup and one resident round of workgroups
+// (2 x 4 waves or 1 x 8 waves per CU)
+static BwwGeom x3_bww_geometry(int H, int Hp, int m, long N, int NW) {
+    BwwGeom g = bww_geometry(H, Hp, m, N);
+    g.TPH = (int)round_up((long)g.JP * g.IB, NW);
+    g.gx = g.HG * g.TPH / NW;
+    int nsplit = xdfm_opt(OPT_BWW_NSPLIT);
+    const int max_split = ceil_div(N, BWW_NC);
+    const int slots = NW == 8 ? 256 : 512;
+    if (nsplit <= 0) nsplit = slots / g.gx > 0 ? slots / g.gx : 1;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > 65535) nsplit = 65535;
+    g.n_per_split = round_up(ceil_div(N, nsplit), BWW_NC);
+    g.nsplit = ceil_div(N, g.n_per_split);
+    return g;
+}
+
 size_t x3_bww_ws_elems(int H, int Hp, int m, long N) {
-    const BwwGeom g = bww_geometry(H, Hp, m, N);
+    const BwwGeom g = x3_bww_geometry(H, Hp, m, N, x3_bww_waves());
     const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);
     return (size_t)w.hdr + (size_t)w.parts + (size_t)w.planes + (size_t)g.slab * g.nsplit;
 }
 
 int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
                    float* dW, hipStream_t st) {
-    BwwGeom g = bww_geometry(H, Hp, m, N);
+    const int NW = x3_bww_waves();
+    BwwGeom g = x3_bww_geometry(H, Hp, m, N, NW);
     const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);
     if ((((size_t)ws) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_w: workspace must be 16-byte aligned");
     float* hdr = ws;
@@ -355,9 +378,13 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     if (rc) return rc;
     }
     if (phase == 0 || phase == 2) {
-    const size_t lds = (size_t)2 * (32 * 4 + 4 * (32 + 8)) * 128;
-    hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4>), dim3(g.gx, g.nsplit), dim3(256), lds, st, planes, w.NP * 4, xp, x0, hdr, Hp,
-                       m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab);
+    const size_t lds = (size_t)2 * (32 * 4 + NW * (32 + 8)) * 128;
+    if (NW == 8)
+        hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, 8>), dim3(g.gx, g.nsplit), dim3(512), lds, st, planes, w.NP * 4, xp, x0,
+                           hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab);
+    else
+        hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, 4>), dim3(g.gx, g.nsplit), dim3(256), lds, st, planes, w.NP * 4, xp, x0,
+                           hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab);
     rc = xdfm_check_launch("cin_level_bwd_w (f16x3)");
     if (rc) return rc;
     }
