@@ -283,6 +283,8 @@ def main():
                 ms_per_step=round(v[0] / max(v[2], 1) * calls_per_step[k] * 1e3, 4),
                 **({"GBps": round(rate / 1e9, 1), "frac_hbm": round(rate / 1e9 / HBM_PEAK_GBS, 4)}
                    if k.endswith("[bytes]") else ({} if k.endswith("passes") else {"TFLOPs": round(rate / 1e12, 2)})))
+        m_, nd_, D_ = cfg["n_sparse"], cfg["n_dense"], cfg["emb_dim"]
+        gather_bytes = 4 * (m_ + nd_) + m_ * (4 * D_ + 4) + 4 * m_ * D_ + 4 * (m_ * D_ + nd_) + 4
         out = {
             "metric": "examples/sec (xDeepFM train step, Criteo-shape synthetic, bs=4096 per GPU)",
             "value": round(B * world * args.steps / dt, 1),
@@ -296,6 +298,10 @@ def main():
                                        args.workload, cfg["n_sparse"], cfg["n_dense"], cfg["emb_dim"],
                                        list(cfg["cin"]), list(cfg["dnn"]), args.vocab, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world},
+            # the step's throughput against the HBM-gather roofline alone (5 308 algorithmic bytes per
+            # example forward at this shape, 8 TB/s): what an embedding-only model could reach per GPU
+            "hbm_gather_roofline": {"bytes_per_example": gather_bytes, "bound_examples_per_sec": round(HBM_PEAK_GBS * 1e9 / gather_bytes * world, 1),
+                                    "frac": round(B * world * args.steps / dt / (HBM_PEAK_GBS * 1e9 / gather_bytes * world), 6)},
             "cin_math": CIN_MATH[math_mode][0],
             "launch": "hip_graph_replay" if replayed else "eager",
             "roofline": roof,
