@@ -48,6 +48,9 @@ WORKLOADS = {
     # BASELINE.json configs[0] (CPU plumbing shape), handy for quick runs
     "criteo_c1": dict(n_sparse=26, n_dense=13, emb_dim=8, cin=(128, 128), dnn=(256, 256), batch=4096),
     # BASELINE.json configs[2]: xDeepFMAttention, same Criteo shape (script-default cin (256,128) -> 256 tokens)
+    # BASELINE.json configs[4] shape on one GPU: Avazu (22 sparse fields, no dense), emb_dim 32, deep CIN.  The config
+    # names a bf16 MFMA path; here it runs the default f16x3 arithmetic (fp32 accuracy at the f16 pipe's rate).
+    "avazu_c5": dict(n_sparse=22, n_dense=0, emb_dim=32, cin=(512, 256, 256, 128), dnn=(256, 256), batch=4096),
     "criteo_c3_attn": dict(n_sparse=26, n_dense=13, emb_dim=16, cin=(256, 128), dnn=(256, 256), batch=4096,
                            model="xDeepFMAttention"),
 }
