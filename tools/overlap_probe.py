@@ -52,6 +52,10 @@ def both_two_streams():
     cur.wait_stream(side)
 
 
+from xdfm_amd import _lib  # noqa: E402
+if len(sys.argv) > 1:
+    _lib.set_option("adam_bx", int(sys.argv[1]))
+print("adam_bx", _lib.get_option("adam_bx"))
 print("eager: cin fwd+bwd %.3f ms, adam sweep %.3f ms, serial %.3f ms, two streams %.3f ms" % (
     timeit(cin), timeit(adam), timeit(lambda: (cin(), adam())), timeit(both_two_streams)), flush=True)
 

@@ -33,6 +33,8 @@ struct AdamBatch { xdfm_adam_tensor t[ADAM_CHUNK]; };
 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     const AdamBatch batch, int t0, double lr, double beta1, double beta2, double eps, float* __restrict__ l2_part) {
+    // gridDim.x blocks per tensor (ADAM_BX by default; fewer = a small footprint that can share the chip with an
+    // MFMA-bound kernel on another stream); the L2 partials keep their ADAM_BX slots per tensor
     const xdfm_adam_tensor& d = batch.t[blockIdx.y];
     const int t = t0 + blockIdx.y;
     float* __restrict__ p = d.param;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     const float g2 = 2.f * l2c;                        // d(l2 * w^2)/dw = 2 l2 w
     float sq = 0.f;
     const long tid = (long)blockIdx.x * ADAM_THREADS + threadIdx.x;
-    const long stride = (long)ADAM_BX * ADAM_THREADS;
+    const long stride = (long)gridDim.x * ADAM_THREADS;
     const bool vec = ((((size_t)p) | ((size_t)m) | ((size_t)v) | ((size_t)g)) & 15) == 0;
     const long n4 = vec ? n / 4 : 0;
     float4* p4 = reinterpret_cast<float4*>(p);
@@ -97,6 +99,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
         __syncthreads();
         if (threadIdx.x == 0) l2_part[(long)t * ADAM_BX + blockIdx.x] = l2c * ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+        if (threadIdx.x < ADAM_BX - gridDim.x && blockIdx.x == 0) l2_part[(long)t * ADAM_BX + gridDim.x + threadIdx.x] = 0.f;
     }
 }
 
@@ -132,7 +135,9 @@ int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double bet
         const int cnt = T - t0 < ADAM_CHUNK ? T - t0 : ADAM_CHUNK;
         for (int k = 0; k < cnt; ++k) batch.t[k] = tensors[t0 + k];
         for (int k = cnt; k < ADAM_CHUNK; ++k) batch.t[k] = tensors[t0];
-        hipLaunchKernelGGL(adam_step_kernel, dim3(ADAM_BX, cnt), dim3(ADAM_THREADS), 0, st, batch, t0, lr, beta1, beta2, eps,
+        int bx = xdfm_opt(OPT_ADAM_BX);
+        if (bx <= 0 || bx > ADAM_BX) bx = ADAM_BX;
+        hipLaunchKernelGGL(adam_step_kernel, dim3(bx, cnt), dim3(ADAM_THREADS), 0, st, batch, t0, lr, beta1, beta2, eps,
                            l2_value ? l2_ws : nullptr);
     }
     if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(1024), 0, st, l2_ws, T * ADAM_BX, l2_value);

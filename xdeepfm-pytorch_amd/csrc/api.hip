@@ -15,8 +15,9 @@ static int g_opts[OPT_COUNT] = {
     /* OPT_X3_BWX_ROWS */ 0,
     /* OPT_X3_WAVES */ 0,
     /* OPT_BWW_PHASE */ 0,
+    /* OPT_ADAM_BX */ 0,
 };
-static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math", "x3_fwd_mt", "x3_bwx_rows", "x3_waves", "bww_phase"};
+static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math", "x3_fwd_mt", "x3_bwx_rows", "x3_waves", "bww_phase", "adam_bx"};
 
 int xdfm_fail(int code, const char* fmt, ...) {
     va_list ap;

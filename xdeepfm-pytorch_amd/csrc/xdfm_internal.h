@@ -24,6 +24,7 @@ enum {
     OPT_X3_BWX_ROWS,     // 0 = auto (256); rows of the contraction per f16x3 dX launch (host side reads it)
     OPT_X3_WAVES,        // 0 = auto (8 waves per workgroup share a weight ring where the piece count allows); 4 = force 4
     OPT_BWW_PHASE,       // 0 = whole dW call; 1 / 2 / 3 = only the pre-passes / the MFMA kernel / the slab sum (f16x3; timing)
+    OPT_ADAM_BX,         // 0 = default (128); blocks per tensor of the Adam kernel
     OPT_COUNT
 };
 
