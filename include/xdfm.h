@@ -16,7 +16,14 @@
  *     and embedding width D:  T[r][n], n = b*D + d, row pitch N = B*D floats.  It is the
  *     reference's [B, R, D] tensor with the R axis outermost, so that the 64 lanes of a
  *     wavefront read consecutive n and one example's D values are contiguous.
- *   - all arithmetic is IEEE fp32 ("dtype f32"); contractions run on v_mfma_f32_32x32x2_f32.
+ *   - operands, accumulators and results are IEEE fp32 ("dtype f32").  The CIN contractions run either on
+ *     v_mfma_f32_32x32x2_f32 or, by default, as three v_mfma_f32_32x32x16_f16 per fp32 product on operands
+ *     split into fp16 hi + lo halves with fp32 accumulation (option "cin_math", see xdfm_set_option);
+ *   - nothing in the library issues a memset (hipMemsetAsync nodes inside a captured graph are not ordered
+ *     reliably on ROCm 7.2 / gfx950); reductions use per-block partials and fixed-order finish kernels.
+ *
+ * ABI 2 (this round): + cin_math option and f16x3 pack / workspace layouts, xdfm_cin_pack_all,
+ * xdfm_cin_level_bwd_x_ex, xdfm_colsum, xdfm_head_fwd/bwd (K8), xdfm_adam_step (K7), xdfm_graph_node_census.
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -28,7 +35,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 1
+#define XDFM_ABI_VERSION 2
 
 enum {
     XDFM_OK = 0,

@@ -46,7 +46,7 @@ def cin_math(request):
 def test_native_library_is_loaded():
     from xdfm_amd import _lib
     lib = _lib.load()
-    assert lib.xdfm_abi_version() == 1
+    assert lib.xdfm_abi_version() == 2
     assert lib.xdfm_device_count() >= 1
     with open("/proc/self/maps") as f:
         assert "libxdfm_hip.so" in f.read()

@@ -65,7 +65,7 @@ class AdamTensor(ctypes.Structure):
                 ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float)]
 
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 
