@@ -305,6 +305,10 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_detail": ("fp32 inputs, weights, accumulators, outputs and optimizer state in both CIN arithmetics; "
+                             + CIN_MATH[math_mode][2] + (". Error against fp64 <= that of the fp32-MFMA kernels "
+                             "(tests/test_gpu_parity.py::test_cin_f16x3_is_as_accurate_as_fp32_mfma); the strict fp32-MFMA "
+                             "measurement of the same K steps is `other_arithmetic`" if math_mode == 1 else "")),
             "config": {"workload": "%s: %d sparse + %d dense, emb_dim %d, cin %s, dnn %s, vocab %d/field, "
                                    "per-GPU batch %d, Adam + L2, fp32" % (
                                        args.workload, cfg["n_sparse"], cfg["n_dense"], cfg["emb_dim"],
