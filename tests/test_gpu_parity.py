@@ -79,7 +79,10 @@ def test_cin_layer_vs_reference_golden(name, cin_math):
                                        (19, 25, 4, (200, 66)),
                                        (1, 26, 16, (256, 128, 128)),             # one example (last batch of an epoch)
                                        (6, 22, 32, (512, 256, 256, 128)),        # BASELINE config-5 layer sizes (H > 256)
-                                       (3, 3, 4, (300, 4))])
+                                       (3, 3, 4, (300, 4)),
+                                       (5, 26, 10, (64, 32)),                    # f16x3 forward with N = 50: one partial wave
+                                       (2, 22, 6, (40,)),                        # N = 12 < 32, odd number of column quads
+                                       (9, 26, 12, (96, 34, 20))])               # Hp = 48, 17: ragged 8-row blocks
 def test_cin_vs_oracle_random(B, m, D, ls, cin_math):
     from deepctr.layers import CIN
     from oracle import xdeepfm_oracle as orc
