@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict_
     const float* src = row < H ? dOut + (long)row * N : (row < H + Hp ? xp + (long)(row - H) * N : x0 + (long)(row - H - Hp) * N);
     float v = 0.f;
     const long base = (long)blockIdx.x * X3_RM_COLS;
-#pragma unroll 4
+#pragma unroll 8
     for (int k = 0; k < X3_RM_COLS / 1024; ++k) {
         const long n = base + ((long)k * 256 + threadIdx.x) * 4;
         if (n < N) {                                    // N % 4 == 0
@@ -317,7 +317,15 @@ __global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const float*
     const int h = (int)(jh % Hpad), j = (int)(jh / Hpad);
     if (i >= Hp || h >= H) return;
     float acc = 0.f;
-    for (int k = 0; k < nslab; ++k) acc += dWt[(long)k * slab_stride + idx];
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {                    // 8 slab loads in flight; the sum keeps its fixed order
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = dWt[(long)(k + q) * slab_stride + idx];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += t[q];
+    }
+    for (; k < nslab; ++k) acc += dWt[(long)k * slab_stride + idx];
     const float sd = hdr[h], sx = hdr[Hpad + i], sz = hdr[Hpad + IPAD + j];
     dW[(long)h * ((long)Hp * m) + (long)i * m + j] = acc * (1.f / sd) * (1.f / sx) * (1.f / sz);
 }
