@@ -78,6 +78,22 @@ __device__ __forceinline__ void x3_split_prod2(float a0, float b0, float a1, flo
     lo = __builtin_convertvector(r, h2);
 }
 
+// max_i |col[i * N]| over rows i = first, first + 2, ... < rows, with 8 loads in flight (a one-load-per-iteration
+// loop pays an L2 round trip per row: 64 of them at H = 128)
+__device__ __forceinline__ float x3_col_absmax(const float* __restrict__ col, long N, int first, int rows) {
+    float mx = 0.f;
+    int i = first;
+    for (; i + 14 < rows; i += 16) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = col[(long)(i + 2 * k) * N];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx = fmaxf(mx, fabsf(v[k]));
+    }
+    for (; i < rows; i += 2) mx = fmaxf(mx, fabsf(col[(long)i * N]));
+    return mx;
+}
+
 // ---------------------------------------------------------------------------------------------
 // |W| maximum: every block stores its partial maximum in header slot X3_HDR_PART + blockIdx.x (plain stores,
 // no zero-initialised cell and no atomics: nothing here depends on a memset node inside a captured graph);
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     if (xp == x0) {
         ap = a0;
     } else {
-        for (int i = hh; i < Hp; i += 2) ap = fmaxf(ap, fabsf(xp[(long)i * N + nc]));
+        ap = x3_col_absmax(xp + nc, N, hh, Hp);
         ap = fmaxf(ap, __shfl_xor(ap, 32)) * nmask;
     }
     const float s0 = x3_pow2_scale(a0, 7), sp = x3_pow2_scale(ap, 7);
@@ -520,7 +536,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
 
     // B operand: dOut[h][n] for all h of this launch, column-scaled and split, in registers
     float dmax = 0.f;
-    for (int q = hh; q < H; q += 2) dmax = fmaxf(dmax, fabsf(dOut[(long)q * N + nc]));
+    dmax = x3_col_absmax(dOut + nc, N, hh, H);
     dmax = fmaxf(dmax, __shfl_xor(dmax, 32)) * nmask;
     const float sD = x3_pow2_scale(dmax, 15);
     h8 bh[HBT], bl[HBT];
