@@ -322,14 +322,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two look-ahead stages must land before LDS is released
 
     // ---- epilogue: remove the scales, bias + activation, FM-layout store --------------------------
+    // The 16 bias values of a row tile are loaded unconditionally (clamped row) and back to back: behind the
+    // per-row condition hipcc issued them one at a time, an L2 round trip each, 16*MT times per wave.
     const float iW = pack[1], i0 = 1.f / s0, ip = 1.f / sp;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+        float bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mb * MT + mt) * 32 + frag_row(r, hh);
+            bv[r] = bias[row < H ? row : H - 1];
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (mb * MT + mt) * 32 + frag_row(r, hh);
             if (row < H && nok && (!(dbg & 1) || acc[mt][r] == 12345.f)) {
-                float v = acc[mt][r] * iW * ip * i0 + bias[row];
+                float v = acc[mt][r] * iW * ip * i0 + bv[r];
                 if (act == XDFM_ACT_RELU) v = fmaxf(v, 0.f);
                 out[(long)row * N + n] = v;
             }
