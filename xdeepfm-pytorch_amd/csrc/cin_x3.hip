@@ -536,10 +536,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
 
     float* x0s = reinterpret_cast<float*>(smem + 3 * STAGE) + wave * (m * 32);     // wave-private x0[j][n0..n0+31]
     float* dx0s = reinterpret_cast<float*>(smem + 3 * STAGE) + (NW + wave) * (m * 32);
-    for (int idx = lane; idx < m * 32; idx += 64) {
-        const long nn = n0 + (idx & 31);
-        x0s[idx] = x0[(long)(idx >> 5) * N + (nn < N ? nn : N - 1)];
-        dx0s[idx] = 0.f;
+    {   // 4 rows of x0 in flight per pass (lane half hh takes the odd rows of a pair)
+        const long nn = n0 + (lane & 31);
+        const long ncl = nn < N ? nn : N - 1;
+        for (int j0 = 0; j0 < m; j0 += 8) {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 2 * k + hh;
+                t[k] = x0[(long)(j < m ? j : m - 1) * N + ncl];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 2 * k + hh;
+                if (j < m) { x0s[j * 32 + (lane & 31)] = t[k]; dx0s[j * 32 + (lane & 31)] = 0.f; }
+            }
+        }
     }
 
     // B operand: dOut[h][n] for all h of this launch, column-scaled and split, in registers
@@ -664,11 +676,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int idx = lane; idx < m * 32; idx += 64) {
-        const long nn = n0 + (idx & 31);
-        if (nn < N) {
-            float* d = dx0 + (long)(idx >> 5) * N + nn;
-            *d = (flags & XDFM_BWX_SET_DX0) ? dx0s[idx] : *d + dx0s[idx];
+    {
+        const long nn = n0 + (lane & 31);
+        const long ncl = nn < N ? nn : N - 1;
+        const bool set = (flags & XDFM_BWX_SET_DX0) != 0;
+        for (int j0 = 0; j0 < m; j0 += 8) {
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                       // the read-modify-write's loads back to back
+                const int j = j0 + 2 * k + hh;
+                t[k] = set ? 0.f : dx0[(long)(j < m ? j : m - 1) * N + ncl];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int j = j0 + 2 * k + hh;
+                if (j < m && nn < N) dx0[(long)j * N + nn] = t[k] + dx0s[j * 32 + (lane & 31)];
+            }
         }
     }
 }

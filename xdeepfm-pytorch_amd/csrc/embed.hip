@@ -128,9 +128,12 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(
     long id = (long)X[(long)b * ldx + cols[j]];
     const int V = vocab[j];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
-    float g = 0.f;
-    if (d_emb_fm) g += d_emb_fm[((long)j * B + b) * D + d];
-    if (d_dnn_in) g += d_dnn_in[(long)b * ((long)m * D + nd) + (long)j * D + d];
+    // both gradient sources are loaded unconditionally (a missing one aliases X and is masked): behind the two
+    // conditions the loads were issued one after the other
+    const float* pe = d_emb_fm ? d_emb_fm + ((long)j * B + b) * D + d : X;
+    const float* pd = d_dnn_in ? d_dnn_in + (long)b * ((long)m * D + nd) + (long)j * D + d : X;
+    const float ge = *pe, gd = *pd;
+    const float g = (d_emb_fm ? ge : 0.f) + (d_dnn_in ? gd : 0.f);
     if (tab_off) atomicAdd(d_flat + tab_off[j] + id * D + d, g);
     if (d == 0 && d_lin && lin_off) atomicAdd(d_flat + lin_off[j] + id, d_lin[b]);
 }
