@@ -111,10 +111,16 @@ __global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t < 8; ++t) v[t] = 0.f;
     if (row < H) {
+        // both float4 halves unconditionally from clamped addresses (N % 4 == 0, N >= 8 here), masked afterwards:
+        // two loads in flight instead of one behind each condition
         const float s = hdr[row];
-        const float* src = dOut + (long)row * N + n;
-        if (n < N) { const float4 a = *reinterpret_cast<const float4*>(src); v[0] = a.x * s; v[1] = a.y * s; v[2] = a.z * s; v[3] = a.w * s; }
-        if (n + 4 < N) { const float4 a = *reinterpret_cast<const float4*>(src + 4); v[4] = a.x * s; v[5] = a.y * s; v[6] = a.z * s; v[7] = a.w * s; }
+        const float* base = dOut + (long)row * N;
+        const long n0c = n < N ? n : N - 4, n1c = n + 4 < N ? n + 4 : N - 4;
+        const float4 a = *reinterpret_cast<const float4*>(base + n0c);
+        const float4 b = *reinterpret_cast<const float4*>(base + n1c);
+        const float m0 = n < N ? s : 0.f, m1 = n + 4 < N ? s : 0.f;
+        v[0] = a.x * m0; v[1] = a.y * m0; v[2] = a.z * m0; v[3] = a.w * m0;
+        v[4] = b.x * m1; v[5] = b.y * m1; v[6] = b.z * m1; v[7] = b.w * m1;
     }
     h8 hi, lo;
 #pragma unroll
