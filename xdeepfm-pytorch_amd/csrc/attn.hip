@@ -234,7 +234,10 @@ __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
 
     float* xrow = Xs + s * XP;
 #pragma unroll
-    for (int d = 0; d < D; ++d) xrow[d] = live ? fm[(long)s * N + (long)b * D + d] : 0.f;
+    for (int d = 0; d < D; ++d) {                        // unconditional load from a clamped row, masked afterwards:
+        const float t = fm[(long)(live ? s : 0) * N + (long)b * D + d];   // behind `live ? load : 0` hipcc issues the loads one by one
+        xrow[d] = live ? t : 0.f;
+    }
 
     for (int layer = 0; layer < n_layers; ++layer) {
         __syncthreads();                                 // previous layer's reads of Ks/Vs/Ws are done
@@ -484,7 +487,11 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             {
                 const float* ml = ml_save + ((((long)layer * B + b) * S + (live ? s : 0)) * NH) * 2;
 #pragma unroll
-                for (int h = 0; h < NH; ++h) { mx[h] = live ? ml[2 * h] : 0.f; il[h] = live ? ml[2 * h + 1] : 0.f; }
+                for (int h = 0; h < NH; ++h) {
+                    const float t0 = ml[2 * h], t1 = ml[2 * h + 1];      // unconditional (clamped row), then masked
+                    mx[h] = live ? t0 : 0.f;
+                    il[h] = live ? t1 : 0.f;
+                }
             }
             __syncthreads();
             // recompute q, k, v and the attention output o
@@ -501,7 +508,10 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             __syncthreads();
             float o[D];
 #pragma unroll
-            for (int d = 0; d < D; ++d) o[d] = live ? orow[d] : 0.f;
+            for (int d = 0; d < D; ++d) {
+                const float t = orow[d];
+                o[d] = live ? t : 0.f;
+            }
             // y = W_o o (+x), LayerNorm backward -> dy
             float dy[D];
             {
