@@ -298,6 +298,78 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(
         part[(long)blockIdx.x * KT + k] = (sm[k] + sm[KT + k]) + (sm[2 * KT + k] + sm[3 * KT + k]);
 }
 
+// vectorised variant (K % 4 == 0, K <= 512, 16-byte aligned): 16 lanes per row, 4 rows per wave at a time, float4
+// loads / stores issued back to back; every lane keeps the partial column sums of its own columns in registers
+// (reduced over the wave's 4 row groups by shuffles at the end, over the 4 waves through LDS) -- the scalar
+// kernel above walks its rows one after the other with an LDS read-modify-write per element
+__global__ __launch_bounds__(HEAD_THREADS) void head_bwd_vec_kernel(
+    const float* __restrict__ pred, const float* __restrict__ y, const float* __restrict__ gloss,
+    const float* __restrict__ u, const float* __restrict__ wu, int Ku, const float* __restrict__ v,
+    const float* __restrict__ wv, int Kv, int B, float* __restrict__ dlin, float* __restrict__ du,
+    float* __restrict__ dv, float* __restrict__ part) {
+    extern __shared__ float sm[];                 // [4 waves][Ku + Kv + 1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 15, grp = lane >> 4;
+    const int KT = Ku + Kv + 1, Ku4 = Ku >> 2, Kv4 = Kv >> 2;
+    const float gl = gloss[0];
+    float4 wu4[8], wv4[8], au[8], av[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = sub + 16 * q;
+        wu4[q] = (u && k < Ku4) ? reinterpret_cast<const float4*>(wu)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        wv4[q] = (v && k < Kv4) ? reinterpret_cast<const float4*>(wv)[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        au[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        av[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float gsum = 0.f;
+    for (int b = (blockIdx.x * 4 + wave) * 4 + grp; b < B; b += HEAD_BLOCKS * 16) {
+        const float p = pred[b], t = y[b];
+        const float pq = (1.f - p) * p;
+        const float g = gl * (p - t) / fmaxf(pq, 1e-12f) * pq;
+        if (sub == 0) { if (dlin) dlin[b] = g; gsum += g; }
+        float4 xu[8], xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = sub + 16 * q;
+            xu[q] = reinterpret_cast<const float4*>(u ? u + (long)b * Ku : pred)[(u && k < Ku4) ? k : 0];
+            xv[q] = reinterpret_cast<const float4*>(v ? v + (long)b * Kv : pred)[(v && k < Kv4) ? k : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = sub + 16 * q;
+            if (u && k < Ku4) {
+                reinterpret_cast<float4*>(du + (long)b * Ku)[k] = make_float4(g * wu4[q].x, g * wu4[q].y, g * wu4[q].z, g * wu4[q].w);
+                au[q].x = fmaf(g, xu[q].x, au[q].x); au[q].y = fmaf(g, xu[q].y, au[q].y);
+                au[q].z = fmaf(g, xu[q].z, au[q].z); au[q].w = fmaf(g, xu[q].w, au[q].w);
+            }
+            if (v && k < Kv4) {
+                reinterpret_cast<float4*>(dv + (long)b * Kv)[k] = make_float4(g * wv4[q].x, g * wv4[q].y, g * wv4[q].z, g * wv4[q].w);
+                av[q].x = fmaf(g, xv[q].x, av[q].x); av[q].y = fmaf(g, xv[q].y, av[q].y);
+                av[q].z = fmaf(g, xv[q].z, av[q].z); av[q].w = fmaf(g, xv[q].w, av[q].w);
+            }
+        }
+    }
+    // sum over the wave's 4 row groups (lanes sub, sub+16, sub+32, sub+48 hold the same columns)
+    float* mine = sm + wave * KT;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float c[8] = {au[q].x, au[q].y, au[q].z, au[q].w, av[q].x, av[q].y, av[q].z, av[q].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { c[e] += __shfl_xor(c[e], 16); c[e] += __shfl_xor(c[e], 32); }
+        const int k = sub + 16 * q;
+        if (grp == 0) {
+            if (u && k < Ku4) { mine[4 * k] = c[0]; mine[4 * k + 1] = c[1]; mine[4 * k + 2] = c[2]; mine[4 * k + 3] = c[3]; }
+            if (v && k < Kv4) { mine[Ku + 4 * k] = c[4]; mine[Ku + 4 * k + 1] = c[5]; mine[Ku + 4 * k + 2] = c[6]; mine[Ku + 4 * k + 3] = c[7]; }
+        }
+    }
+    gsum += __shfl_xor(gsum, 16);
+    gsum += __shfl_xor(gsum, 32);
+    if (lane == 0) mine[Ku + Kv] = gsum;
+    __syncthreads();
+    for (int k = threadIdx.x; k < KT; k += HEAD_THREADS)
+        part[(long)blockIdx.x * KT + k] = (sm[k] + sm[KT + k]) + (sm[2 * KT + k] + sm[3 * KT + k]);
+}
+
 __global__ void head_bwd_finish_kernel(const float* __restrict__ part, int KT, float* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= KT) return;
@@ -338,8 +410,14 @@ int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, const f
     const size_t lds = (size_t)4 * KT * sizeof(float);
     XDFM_REQUIRE(lds <= 64 * 1024, "head_bwd: Ku + Kv = %d too large", ku + kv);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), lds, st, pred, y, gloss, u, wu, ku, v, wv, kv,
-                       B, dlin, du, dv, ws);
+    const bool vec = ku % 4 == 0 && kv % 4 == 0 && ku <= 512 && kv <= 512 &&
+                     ((((size_t)u) | ((size_t)v) | ((size_t)wu) | ((size_t)wv) | ((size_t)du) | ((size_t)dv)) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), lds, st, pred, y, gloss, u, wu, ku, v,
+                           wv, kv, B, dlin, du, dv, ws);
+    else
+        hipLaunchKernelGGL(head_bwd_kernel, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), lds, st, pred, y, gloss, u, wu, ku, v, wv,
+                           kv, B, dlin, du, dv, ws);
     hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(ceil_div(KT, 256)), dim3(256), 0, st, ws, KT, grads);
     return xdfm_check_launch("head_bwd");
 }
