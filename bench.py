@@ -150,6 +150,27 @@ def cpu_baseline(cfg, vocab_size, rows, steps):
                        % (steps, rows, dt / steps))
 
 
+PMC_KERNEL = {"cin_level_bwd_x": "cin_bwd_x3_kernel", "cin_level_bwd_w": "cin_bwd_w_x3_kernel",
+              "cin_level_fwd": "cin_fwd_x3_kernel"}
+
+
+def pmc_traffic(bracket, workload, math_mode):
+    """HBM-side bytes per launch of the roofline kernel.  Performance counters cannot be read from inside this process,
+    so the figure comes from the committed rocprofv3 --pmc passes over tools/pmc_cin.py (same kernels, same shapes as
+    the default workload: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950) -- profiles/r01_pmc_cin_traffic.{md,json}.  null for any other workload or arithmetic."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_cin_traffic.json")
+    if workload != "criteo_c2" or math_mode != 1 or bracket not in PMC_KERNEL or not os.path.exists(path):
+        return {}
+    rows = [v for k, v in json.load(open(path)).items() if k.startswith(PMC_KERNEL[bracket])]
+    n = sum(v["launches"] for v in rows)
+    if not n:
+        return {}
+    total = sum(v["total_bytes"] * v["launches"] for v in rows) / n
+    return dict(traffic=round(total), traffic_unit="bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, mean over the levels)",
+                traffic_source="profiles/r01_pmc_cin_traffic.md")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -287,6 +308,7 @@ def main():
                         unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
                         launches=n, avg_ms=round(secs / n * 1e3, 4),
                         note="fp32-equivalent FLOPs (2*H*Hp*m*N per launch); " + CIN_MATH[math_mode][2])
+            roof.update(pmc_traffic(name, args.workload, math_mode))
         kernels = {}
         calls_per_step = {k: v[2] / prof_steps for k, v in per_kernel.items()}
         for k, v in sorted(per_kernel.items()):
