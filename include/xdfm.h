@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 2
+#define XDFM_ABI_VERSION 3
 
 enum {
     XDFM_OK = 0,
@@ -103,6 +103,17 @@ int xdfm_embed_scatter_bwd(const float* X, long ldx, int B,
                            const float* d_emb_fm, const float* d_dnn_in, const float* d_lin,
                            float* d_flat, const long* tab_off, const long* lin_off, float* d_dense_w,
                            void* stream);
+/* Same, and marks[e >> 2] = 1 for every element offset e of d_flat (16-byte aligned) that received a gradient
+ * -- one byte per 16-byte chunk; d_dense_w must then point into d_flat too.  A caller that keeps d_flat across
+ * steps hands the marks to K7 (xdfm_adam_tensor.grad_marks), which reads and re-zeroes only the marked chunks:
+ * the table-sized zero fill of the gradients (optim.zero_grad over dense [V, D] gradients) and
+ * the table-sized gradient read of the optimizer step both shrink to the rows the batch touched. */
+int xdfm_embed_scatter_bwd_marked(const float* X, long ldx, int B,
+                                  const int* cols, const int* vocab, int m, int D,
+                                  const int* dense_cols, int nd,
+                                  const float* d_emb_fm, const float* d_dnn_in, const float* d_lin,
+                                  float* d_flat, const long* tab_off, const long* lin_off, float* d_dense_w,
+                                  unsigned char* marks, void* stream);
 
 /* ------------------------------------------------------------------ CIN level (K3 / K4)
  * One level of deepctr/layers/interaction.py:216-243 (same loop in
@@ -239,15 +250,22 @@ int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, const f
  * parameter, already incremented for this step.
  * l2 > 0 in a descriptor: the kernel uses g + 2*l2*w as the gradient (the term l2 * sum(w^2) of
  * basemodel.py:412-428 with unit upstream gradient); with l2_value != NULL it also returns
- * sum_t l2_t * sum(w_t^2) of the weights BEFORE the update (l2_ws: xdfm_adam_step_ws_elems(T) floats). */
+ * sum_t l2_t * sum(w_t^2) of the weights BEFORE the update (l2_ws: xdfm_adam_step_ws_elems(T) floats).
+ * ABI 3 added grad_marks. */
 typedef struct {
     float* param;
-    const float* grad;
+    float* grad;
     float* exp_avg;
     float* exp_avg_sq;
     const float* step;
     long numel;
     float l2;
+    /* NULL: grad is read in full and left alone.  Otherwise one byte per 16-byte chunk of grad (which must be
+     * 16-byte aligned; see xdfm_embed_scatter_bwd_marked): a chunk whose mark is 0 is taken as zeros without
+     * being read; a marked chunk is read, then overwritten with zeros, and its mark cleared -- after the step
+     * the gradient buffer is all zeros again, ready for the next scatter.  The numel % 4 tail elements are always
+     * read and zeroed. */
+    unsigned char* grad_marks;
 } xdfm_adam_tensor;
 size_t xdfm_adam_step_ws_elems(int T);
 int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double beta1, double beta2, double eps,

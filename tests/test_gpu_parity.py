@@ -5,6 +5,8 @@ Tolerances (fp32 everywhere): forward values rtol 2e-5 / atol 2e-6 -- the MFMA c
 K = Hp*m products in a different order than ATen; gradients rtol 2e-4 with an absolute floor of
 2e-5 x max|expected| (dW sums B*D = thousands of terms with fp32 atomics in arbitrary order).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -46,7 +48,7 @@ def cin_math(request):
 def test_native_library_is_loaded():
     from xdfm_amd import _lib
     lib = _lib.load()
-    assert lib.xdfm_abi_version() == 2
+    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 3
     assert lib.xdfm_device_count() >= 1
     with open("/proc/self/maps") as f:
         assert "libxdfm_hip.so" in f.read()
@@ -599,6 +601,122 @@ def test_graph_replay_of_train_step_matches_eager_launches():
         assert n > 20 and n_memset == 0 and n_other == 0
     np.testing.assert_allclose(l_g, l_e, rtol=2e-5)
     for (k, a), (_, b) in zip(m_g.state_dict().items(), m_e.state_dict().items()):
+        close(a, b.cpu().numpy(), rtol=2e-3, atol=2e-6, msg=k)
+
+
+def test_marked_gradients_skip_untouched_rows_bit_exactly():
+    """xdfm_embed_scatter_bwd_marked + xdfm_adam_tensor.grad_marks: the scatter marks the 16-byte
+    chunks of the flat gradient buffer it adds to; K7 given the marks must produce the very same parameters and
+    moments as K7 reading the full dense gradient (bit-exact: same arithmetic, zeros not read instead of read), and
+    must leave the gradient buffer and the marks all zero.  Through the C ABI."""
+    import ctypes
+    from xdfm_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    m, D, nd, B = 5, 12, 3, 333
+    vocab = [97, 1000, 13, 4096, 50]
+    X = torch.cat([torch.stack([torch.randint(0, v, (B,), generator=g) for v in vocab], 1).float(),
+                   torch.rand(B, nd, generator=g)], 1).to(dev)
+    sizes = [v * D for v in vocab] + list(vocab) + [nd]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    total = off
+    flat = torch.zeros(total, device=dev)
+    marks = torch.zeros(total // 4 + 2, dtype=torch.uint8, device=dev)
+    i32 = dict(dtype=torch.int32, device=dev)
+    cols, voc, dcols = torch.arange(m, **i32), torch.tensor(vocab, **i32), torch.arange(m, m + nd, **i32)
+    off_dev = torch.tensor(offs[:2 * m], dtype=torch.int64, device=dev)
+    d_emb = torch.randn(m, B * D, generator=g).to(dev)
+    d_dnn = torch.randn(B, m * D + nd, generator=g).to(dev)
+    d_lin = torch.randn(B, generator=g).to(dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d_w = flat[offs[-1]:offs[-1] + nd]
+    _lib.check(lib.xdfm_embed_scatter_bwd_marked(P(X), X.stride(0), B, P(cols), P(voc), m, D, P(dcols), nd, P(d_emb),
+                                                 P(d_dnn), P(d_lin), P(flat), P(off_dev[:m]), P(off_dev[m:]), P(d_w),
+                                                 P(marks), st), "scatter marked")
+    plain = torch.zeros_like(flat)
+    _lib.check(lib.xdfm_embed_scatter_bwd(P(X), X.stride(0), B, P(cols), P(voc), m, D, P(dcols), nd, P(d_emb), P(d_dnn),
+                                          P(d_lin), P(plain), P(off_dev[:m]), P(off_dev[m:]),
+                                          P(plain[offs[-1]:offs[-1] + nd]), st), "scatter")
+    close(flat, plain.cpu().numpy(), rtol=1e-4, atol=3e-5)            # same sums (atomics order differs)
+    chunk_nonzero = (flat.view(-1, 4) != 0).any(1)
+    mk = marks[:total // 4].bool()
+    assert bool((mk | ~chunk_nonzero).all())                          # every chunk that holds a gradient is marked
+    touched_rows = sum(len(set(X[:, j].long().tolist())) for j in range(m))
+    assert int(mk.sum()) <= touched_rows * (D // 4 + 1) + nd          # ... and only chunks of touched rows are
+
+    # K7 over the same gradients: marked (sparse read) against unmarked (dense read) descriptors
+    T_ = len(sizes)
+    torch.manual_seed(5)
+    pa = [torch.randn(n, device=dev) * 0.05 for n in sizes]
+    ma = [torch.randn(n, device=dev) * 0.01 for n in sizes]
+    va = [torch.rand(n, device=dev) * 1e-4 for n in sizes]
+    pb, mb, vb = [t.clone() for t in pa], [t.clone() for t in ma], [t.clone() for t in va]
+    step = torch.full((1,), 3.0, device=dev)
+    dense_g, before = flat.clone(), flat.clone()
+
+    def run(ps, ms, vs, gbuf, mark_buf):
+        arr = (_lib.AdamTensor * T_)()
+        for k in range(T_):
+            arr[k].param, arr[k].exp_avg, arr[k].exp_avg_sq = ps[k].data_ptr(), ms[k].data_ptr(), vs[k].data_ptr()
+            arr[k].grad = gbuf.data_ptr() + 4 * offs[k]
+            arr[k].step, arr[k].numel, arr[k].l2 = step.data_ptr(), sizes[k], 1e-4 if k < m else 0.0
+            arr[k].grad_marks = (mark_buf.data_ptr() + offs[k] // 4) if mark_buf is not None else None
+        ws = torch.empty(lib.xdfm_adam_step_ws_elems(T_), device=dev)
+        val = torch.empty(1, device=dev)
+        _lib.check(lib.xdfm_adam_step(ctypes.cast(arr, ctypes.c_void_p), T_, 1e-3, 0.9, 0.999, 1e-8, P(ws), P(val), st), "adam")
+        return val
+
+    v_sparse = run(pa, ma, va, flat, marks)
+    v_dense = run(pb, mb, vb, dense_g, None)
+    torch.cuda.synchronize()
+    assert float(v_sparse) == float(v_dense)
+    bad = [(k, nm, int((a[k] != b[k]).sum()), float((a[k] - b[k]).abs().max()), (a[k] != b[k]).nonzero()[:6].flatten().tolist())
+           for k in range(T_) for nm, a, b in (("p", pa, pb), ("m", ma, mb), ("v", va, vb)) if not torch.equal(a[k], b[k])]
+    assert not bad, bad
+    assert float(flat.abs().max()) == 0.0 and int(marks.max()) == 0
+    assert torch.equal(dense_g, before)                               # the dense read leaves g alone
+
+
+def test_train_step_keeps_table_gradients_clean_without_table_sized_fills():
+    """The model's own train step (eager and graph-replayed) on the kept gradient buffer (ops.GradArena): same
+    losses and parameters as with a fresh zero-filled buffer per step (XDFM_GRAD_ARENA=0), never the slow full
+    clear, and buffer + marks all zero after every step."""
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    vocab, nd, D = [50, 31, 77, 12, 9, 40], 3, 8
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(nd)]
+
+    def run(arena):
+        os.environ["XDFM_GRAD_ARENA"] = "1" if arena else "0"
+        try:
+            model = xDeepFM(cols, cols, dnn_hidden_units=(32, 16), cin_layer_size=(16, 8), l2_reg_dnn=1e-5, device=dev)
+            model.compile("adam", "binary_crossentropy", metrics=[])
+            model.train()
+            losses = []
+            for s in range(9):
+                X, y = orc.synthetic_batch(256 if s != 4 else 100, vocab, nd, seed=300 + s)
+                out = model.train_on_batch(T(X).to(dev), T(y).to(dev))
+                losses.append(float(out[2].detach().reshape(-1)[0]))
+                for a in model._plan.arenas():
+                    assert not a.pending and a.full_clears == 0
+                    assert float(a.flat.abs().max()) == 0.0 and int(a.marks.max()) == 0
+            return model, losses
+        finally:
+            os.environ.pop("XDFM_GRAD_ARENA", None)
+
+    m_a, l_a = run(True)
+    m_z, l_z = run(False)
+    assert len(m_a._plan.arenas()) == 1 and len(m_z._plan.arenas()) == 0
+    assert m_a.__dict__["_graphed_step"].replays >= 3
+    np.testing.assert_allclose(l_a, l_z, rtol=2e-5)
+    for (k, a), (_, b) in zip(m_a.state_dict().items(), m_z.state_dict().items()):
         close(a, b.cpu().numpy(), rtol=2e-3, atol=2e-6, msg=k)
 
 

@@ -21,9 +21,12 @@
 
 struct AdamCoef { float w1, b2, w2, lr, eps; };
 
+// The fusions are spelled out and the compiler's own contraction is off: left to itself it fuses differently in
+// the marked and the dense loop below, and the two must give the same bits.
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt, const AdamCoef& c) {
-    m = m + c.w1 * (g - m);
-    v = c.b2 * v + c.w2 * g * g;
+#pragma clang fp contract(off)
+    m = fmaf(c.w1, g - m, m);
+    v = fmaf(c.w2 * g, g, c.b2 * v);
     const float denom = sqrtf(v) / bc2_sqrt + c.eps;
     p -= step_size * m / denom;
 }
@@ -40,7 +43,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     float* __restrict__ p = d.param;
     float* __restrict__ m = d.exp_avg;
     float* __restrict__ v = d.exp_avg_sq;
-    const float* __restrict__ g = d.grad;
+    float* __restrict__ g = d.grad;
+    unsigned char* __restrict__ marks = d.grad_marks;
     const long n = d.numel;
     const float* l2 = &d.l2;
     // bias corrections in double as ATen does, once per block (two double pow() per THREAD cost more than
@@ -64,8 +68,47 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     float4* p4 = reinterpret_cast<float4*>(p);
     float4* m4 = reinterpret_cast<float4*>(m);
     float4* v4 = reinterpret_cast<float4*>(v);
-    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* g4 = reinterpret_cast<float4*>(g);
     long i = tid;
+    if (marks) {
+        // sparse gradient: a chunk's mark says whether the scatter touched it; unmarked chunks are zeros by
+        // construction and are not read, marked ones are read, re-zeroed and unmarked (each lane owns its chunk's
+        // mark, so nothing races).  The mark bytes are loaded first, the gradient loads sit behind them.
+        // The zero is opaque to the compiler: with a literal 0 it folds fmaf(2*l2, w, 0) into a product and then
+        // contracts that product into the next subtraction, which rounds differently from the dense path -- with
+        // the same instruction sequence both paths give the same bits.
+        float zf;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
+        const float4 zero4 = make_float4(zf, zf, zf, zf);
+        for (; i + stride < n4; i += 2 * stride) {
+            const unsigned char ka = marks[i], kb = marks[i + stride];
+            float4 pa = p4[i], ma = m4[i], va = v4[i];
+            float4 pb = p4[i + stride], mb = m4[i + stride], vb = v4[i + stride];
+            float4 ga = zero4, gb = zero4;
+            if (ka) { ga = g4[i]; g4[i] = zero4; marks[i] = 0; }
+            if (kb) { gb = g4[i + stride]; g4[i + stride] = zero4; marks[i + stride] = 0; }
+            sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w) + (pb.x * pb.x + pb.y * pb.y) + (pb.z * pb.z + pb.w * pb.w);
+            ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+            gb.x = fmaf(g2, pb.x, gb.x); gb.y = fmaf(g2, pb.y, gb.y); gb.z = fmaf(g2, pb.z, gb.z); gb.w = fmaf(g2, pb.w, gb.w);
+            adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+            adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+            adam_one(pb.x, gb.x, mb.x, vb.x, step_size, bc2_sqrt, c); adam_one(pb.y, gb.y, mb.y, vb.y, step_size, bc2_sqrt, c);
+            adam_one(pb.z, gb.z, mb.z, vb.z, step_size, bc2_sqrt, c); adam_one(pb.w, gb.w, mb.w, vb.w, step_size, bc2_sqrt, c);
+            p4[i] = pa; m4[i] = ma; v4[i] = va;
+            p4[i + stride] = pb; m4[i + stride] = mb; v4[i + stride] = vb;
+        }
+        for (; i < n4; i += stride) {
+            const unsigned char ka = marks[i];
+            float4 pa = p4[i], ma = m4[i], va = v4[i];
+            float4 ga = zero4;
+            if (ka) { ga = g4[i]; g4[i] = zero4; marks[i] = 0; }
+            sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+            ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+            adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+            adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+            p4[i] = pa; m4[i] = ma; v4[i] = va;
+        }
+    }
     for (; i + stride < n4; i += 2 * stride) {            // two float4 per array in flight
         float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
         float4 pb = p4[i + stride], gb = g4[i + stride], mb = m4[i + stride], vb = v4[i + stride];
@@ -92,6 +135,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
         sq = fmaf(pa, pa, sq);
         adam_one(pa, fmaf(g2, pa, g[k]), ma, va, step_size, bc2_sqrt, c);
         p[k] = pa; m[k] = ma; v[k] = va;
+        if (marks) { g[k] = 0.f; marks[k >> 2] = 0; }
     }
     if (l2_part) {                                     // fixed-order block reduction of the squares
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
@@ -129,6 +173,10 @@ int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double bet
     for (int t = 0; t < T; ++t)
         XDFM_REQUIRE(tensors[t].param && tensors[t].grad && tensors[t].exp_avg && tensors[t].exp_avg_sq && tensors[t].step &&
                          tensors[t].numel >= 0, "adam_step: tensor %d has a null pointer", t);
+    for (int t = 0; t < T; ++t)
+        XDFM_REQUIRE(!tensors[t].grad_marks || ((((size_t)tensors[t].param) | ((size_t)tensors[t].grad) | ((size_t)tensors[t].exp_avg) |
+                                                  ((size_t)tensors[t].exp_avg_sq)) & 15) == 0,
+                     "adam_step: tensor %d has grad_marks but a pointer that is not 16-byte aligned", t);
     hipStream_t st = (hipStream_t)stream;
     for (int t0 = 0; t0 < T; t0 += ADAM_CHUNK) {
         AdamBatch batch;

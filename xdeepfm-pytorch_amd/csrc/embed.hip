@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(
     const float* __restrict__ X, long ldx, int B, const int* __restrict__ cols, const int* __restrict__ vocab, int m,
     int D, int nd, const float* __restrict__ d_emb_fm, const float* __restrict__ d_dnn_in,
     const float* __restrict__ d_lin, float* __restrict__ d_flat, const long* __restrict__ tab_off,
-    const long* __restrict__ lin_off) {
+    const long* __restrict__ lin_off, unsigned char* __restrict__ marks) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)B * m * D;
     if (idx >= total) return;
@@ -134,15 +134,26 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(
     const float* pd = d_dnn_in ? d_dnn_in + (long)b * ((long)m * D + nd) + (long)j * D + d : X;
     const float ge = *pe, gd = *pd;
     const float g = (d_emb_fm ? ge : 0.f) + (d_dnn_in ? gd : 0.f);
-    if (tab_off) atomicAdd(d_flat + tab_off[j] + id * D + d, g);
-    if (d == 0 && d_lin && lin_off) atomicAdd(d_flat + lin_off[j] + id, d_lin[b]);
+    // marks: one byte per 16-byte chunk of d_flat, set where a gradient landed (several threads may store the
+    // same 1) -- K7 then reads, and re-zeroes, only the marked chunks (xdfm_adam_tensor.grad_marks)
+    if (tab_off) {
+        const long e = tab_off[j] + id * D + d;
+        atomicAdd(d_flat + e, g);
+        if (marks) marks[e >> 2] = 1;
+    }
+    if (d == 0 && d_lin && lin_off) {
+        const long e = lin_off[j] + id;
+        atomicAdd(d_flat + e, d_lin[b]);
+        if (marks) marks[e >> 2] = 1;
+    }
 }
 
 // d(linear_model.weight)[k] += sum_b X[b][dense_cols[k]] * d_lin[b]
 __global__ __launch_bounds__(256) void dense_w_grad_kernel(const float* __restrict__ X, long ldx, int B,
                                                           const int* __restrict__ dense_cols, int nd,
                                                           const float* __restrict__ d_lin,
-                                                          float* __restrict__ d_dense_w) {
+                                                          float* __restrict__ d_dense_w,
+                                                          unsigned char* __restrict__ marks, long mark_base) {
     const int k = blockIdx.y;
     const int col = dense_cols[k];
     float part = 0.f;
@@ -152,7 +163,10 @@ __global__ __launch_bounds__(256) void dense_w_grad_kernel(const float* __restri
     __shared__ float wsum[4];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&d_dense_w[k], wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) {
+        atomicAdd(&d_dense_w[k], wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+        if (marks) marks[(mark_base + k) >> 2] = 1;
+    }
 }
 
 extern "C" {
@@ -192,14 +206,24 @@ int xdfm_embed_scatter_bwd(const float* X, long ldx, int B, const int* cols, con
                            const int* dense_cols, int nd, const float* d_emb_fm, const float* d_dnn_in,
                            const float* d_lin, float* d_flat, const long* tab_off, const long* lin_off,
                            float* d_dense_w, void* stream) {
+    return xdfm_embed_scatter_bwd_marked(X, ldx, B, cols, vocab, m, D, dense_cols, nd, d_emb_fm, d_dnn_in, d_lin, d_flat,
+                                         tab_off, lin_off, d_dense_w, nullptr, stream);
+}
+
+int xdfm_embed_scatter_bwd_marked(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
+                                  const int* dense_cols, int nd, const float* d_emb_fm, const float* d_dnn_in,
+                                  const float* d_lin, float* d_flat, const long* tab_off, const long* lin_off,
+                                  float* d_dense_w, unsigned char* marks, void* stream) {
     XDFM_REQUIRE(X && cols && vocab, "embed_scatter_bwd: null pointer");
+    XDFM_REQUIRE(!marks || (d_flat && (((size_t)d_flat) & 15) == 0), "embed_scatter_bwd: marks need a 16-byte aligned d_flat");
+    XDFM_REQUIRE(!marks || !d_dense_w || d_dense_w >= d_flat, "embed_scatter_bwd: with marks d_dense_w must lie inside d_flat");
     XDFM_REQUIRE(d_flat || (!tab_off && !lin_off), "embed_scatter_bwd: offsets without a gradient buffer");
     XDFM_REQUIRE(B > 0 && m > 0 && D > 0 && nd >= 0, "embed_scatter_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
     if (tab_off || (d_lin && lin_off)) {
         const long total = (long)B * m * D;
         hipLaunchKernelGGL(embed_scatter_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, X, ldx, B, cols, vocab,
-                           m, D, nd, d_emb_fm, d_dnn_in, d_lin, d_flat, tab_off, lin_off);
+                           m, D, nd, d_emb_fm, d_dnn_in, d_lin, d_flat, tab_off, lin_off, marks);
         int rc = xdfm_check_launch("embed_scatter_bwd");
         if (rc) return rc;
     }
@@ -208,7 +232,7 @@ int xdfm_embed_scatter_bwd(const float* X, long ldx, int B, const int* cols, con
         int gx = ceil_div(B, 256);
         if (gx > 64) gx = 64;
         hipLaunchKernelGGL(dense_w_grad_kernel, dim3(gx, nd), dim3(256), 0, st, X, ldx, B, dense_cols, nd, d_lin,
-                           d_dense_w);
+                           d_dense_w, marks, marks ? (long)(d_dense_w - d_flat) : 0L);
         return xdfm_check_launch("embed_scatter_bwd dense_w");
     }
     return XDFM_OK;

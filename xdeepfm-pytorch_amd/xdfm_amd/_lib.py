@@ -26,6 +26,7 @@ SIGNATURES = {
     "xdfm_graph_node_census": (c_int, [P, P, P, P]),
     "xdfm_embed_gather_fwd": (c_int, [P, c_long, c_int, P, P, P, P, c_int, c_int, P, P, c_int, P, P, P, P, P]),
     "xdfm_embed_scatter_bwd": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P]),
+    "xdfm_embed_scatter_bwd_marked": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P]),
     "xdfm_cin_fwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_fwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "xdfm_cin_pack_all_supported": (c_int, [c_int, c_int, c_int]),
@@ -62,10 +63,10 @@ class PackJob(ctypes.Structure):
 class AdamTensor(ctypes.Structure):
     """xdfm_adam_tensor of include/xdfm.h"""
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
-                ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float)]
+                ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float), ("grad_marks", c_void_p)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 

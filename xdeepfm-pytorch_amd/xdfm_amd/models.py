@@ -166,6 +166,7 @@ class BaseModel(nn.Module):
         """(emb_fm [m, B*D], dnn_in [B, m*D+nd], linear_logit [B,1]) from ONE gather launch
         (input_from_feature_columns + linear_model + both concatenations of the reference forward)."""
         plan = self._gather_plan()
+        self._use_grad_arena(plan)
         if not self._sparse_cols:
             raise NotImplementedError("the xDeepFM path needs at least one SparseFeat")
         tabs = [self.embedding_dict[fc.embedding_name].weight for fc in self._sparse_cols]
@@ -328,6 +329,13 @@ class BaseModel(nn.Module):
     # Row-parallel step with the L2 term in K7, in two halves.  The first (forward, loss, backward down to the
     # row gradients of the gather) contains no collective, so it can be replayed from a HIP graph; the second
     # exchanges the rows, scatters, all-reduces the dense gradients and runs the optimizer, eagerly.
+    def _use_grad_arena(self, plan):
+        """Keep the dense table gradients across steps when the optimizer can consume them by their marks."""
+        from .optim import TableAdam
+        plan.arena_on = isinstance(getattr(self, "optim", None), TableAdam)
+        if plan.arena_on and plan not in self.optim.grad_sources:
+            self.optim.grad_sources.append(plan)
+
     def _split_step_first(self, x, y):
         self.optim.zero_grad()
         plan = self._gather_plan()

@@ -5,6 +5,7 @@ arithmetic step of the embedding gather and of the CIN stack runs in the hand-wr
 All ops require float32 CUDA (ROCm) tensors and raise otherwise -- there is no CPU path.
 """
 import ctypes
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -72,6 +73,8 @@ class EmbedPlan:
         self.dp = None            # set by xdfm_amd.dist to exchange row gradients across ranks
         self.reg_defer = None     # (gscale, L2Plan) left by L2Reg.backward: table L2 gradient still owed
         self.stash = None         # list: gather backwards park their inputs here instead of scattering (split step)
+        self.arena_on = False     # the model's train step sets this when its optimizer consumes marked gradients
+        self._arenas = {}
 
     def on(self, device):
         key = str(device)
@@ -98,12 +101,26 @@ class EmbedPlan:
         if hit is None:
             sizes = [sh[0] * sh[1] for sh in shapes]
             offs, off = [], 0
-            for n in sizes:
+            for n in sizes:                  # every gradient starts on a 16-byte boundary (K7's float4 path; marks)
                 offs.append(off)
-                off += n
+                off += (n + 3) // 4 * 4
             hit = (sizes, offs, off, torch.tensor(offs, dtype=torch.int64, device=device))
             self._off_cache[key] = hit
         return hit
+
+    def arena(self, shapes, device):
+        """The flat gradient buffer kept ACROSS steps (GradArena), or None when that mode is off."""
+        if not self.arena_on or os.environ.get("XDFM_GRAD_ARENA", "1") == "0":
+            return None
+        key = (tuple(shapes), str(device))
+        hit = self._arenas.get(key)
+        if hit is None:
+            _, _, total, _ = self.grad_layout(shapes, device)
+            hit = self._arenas[key] = GradArena(total + max(self.nd, 1), device)
+        return hit
+
+    def arenas(self):
+        return list(self._arenas.values())
 
     def check_ids(self, device) -> bool:
         """True when a gather since the last call saw an id outside [0, vocab) (syncs the stream)."""
@@ -111,6 +128,48 @@ class EmbedPlan:
         bad = bool(flag.item())
         flag.zero_()
         return bad
+
+
+class GradArena:
+    """Dense table gradients without the table-sized passes (`optim.zero_grad` of dense [V, D] grads).
+
+    The reference's tables carry dense gradients (deepctr/inputs.py:168), all zeros except the <= B rows per table a
+    batch touches; a step pays a table-sized zero fill and a table-sized gradient read in the optimizer for them.
+    Here the flat gradient buffer lives across steps: the scatter marks the 16-byte chunks it adds to
+    (`xdfm_embed_scatter_bwd_marked`), K7 reads only marked chunks and writes zeros back (`xdfm_adam_tensor.grad_marks`),
+    so the buffer is clean again when the step ends.  `pending` = byte offsets of the views handed to autograd that
+    no optimizer step has consumed yet; a scatter that finds leftovers (a step without K7, a gradient that autograd
+    copied instead of adopting) clears everything the slow way first -- correctness never depends on the fast path.
+    Consequence worth knowing: after `optim.step()` the tables' `.grad` read zeros (they are views of this buffer)."""
+
+    def __init__(self, numel, device):
+        self.flat = torch.zeros(numel, dtype=torch.float32, device=device)
+        self.marks = torch.zeros(numel // 4 + 2, dtype=torch.uint8, device=device)
+        self.base, self.nbytes = self.flat.data_ptr(), numel * 4
+        self.pending = set()
+        self.full_clears = 0
+
+    def begin(self):
+        if self.pending:
+            self.flat.zero_()
+            self.marks.zero_()
+            self.pending.clear()
+            self.full_clears += 1
+
+    def hand_out(self, views):
+        for v in views:
+            if v is not None:
+                self.pending.add(v.data_ptr() - self.base)
+
+    def marks_ptr(self, grad_ptr):
+        """Address of the mark bytes of a gradient that is one of this arena's views (else None)."""
+        off = grad_ptr - self.base
+        if 0 <= off < self.nbytes and off % 16 == 0 and off in self.pending:
+            return self.marks.data_ptr() + off // 16
+        return None
+
+    def consumed(self, grad_ptr):
+        self.pending.discard(grad_ptr - self.base)
 
 
 class EmbedGather(torch.autograd.Function):
@@ -160,12 +219,12 @@ class EmbedGather(torch.autograd.Function):
             # it runs after the exchange, outside the captured part -- see apply_stashed_scatter
             plan.stash.append((plan, X, d_emb, d_dnn, d_lin, ctx.has_lin, ctx.shapes, tables, ctx.needs_input_grad[1]))
             return (None, None, None, None) + (None,) * len(tables)
-        grads, d_w = EmbedGather.scatter(plan, X, d_emb, d_dnn, d_lin, ctx.has_lin, ctx.shapes, tables)
         need_w = ctx.needs_input_grad[1]
+        grads, d_w = EmbedGather.scatter(plan, X, d_emb, d_dnn, d_lin, ctx.has_lin, ctx.shapes, tables, need_w)
         return (None, d_w if (need_w and plan.nd) else None, None, None) + tuple(grads)
 
     @staticmethod
-    def scatter(plan, X, d_emb, d_dnn, d_lin, has_lin, shapes, tables):
+    def scatter(plan, X, d_emb, d_dnn, d_lin, has_lin, shapes, tables, need_w=True):
         """Dense table gradients (views of one flat buffer) and the dense-weight gradient from the row gradients."""
         lib = _lib.load()
         m, D, nd = plan.m, plan.D, plan.nd
@@ -175,7 +234,12 @@ class EmbedGather(torch.autograd.Function):
         # starts as zeros, or -- when L2Reg.backward deferred the tables' L2 term to us -- as
         # 2*l2*gscale*w, which saves a memset, a table-sized temporary and one add per table.
         defer, plan.reg_defer = plan.reg_defer, None
-        if defer is not None:
+        arena = plan.arena(shapes, dev) if defer is None and all(t.grad is None for t in tables) else None
+        marks = None
+        if arena is not None:
+            arena.begin()
+            flat, marks = arena.flat, arena.marks
+        elif defer is not None:
             gscale, l2plan = defer
             flat = torch.empty(total + max(nd, 1), dtype=torch.float32, device=dev)
             flat[total:].zero_()
@@ -186,6 +250,8 @@ class EmbedGather(torch.autograd.Function):
             flat = torch.zeros(total + max(nd, 1), dtype=torch.float32, device=dev)
         grads = [flat[o:o + n].view(sh) for o, n, sh in zip(offs, sizes, shapes)]
         d_w = flat[total:total + nd].view(nd, 1) if nd else None
+        if arena is not None:
+            arena.hand_out(grads + ([d_w] if need_w else []))
         cols, vocab, dcols, _ = plan.on(dev)
         tab_off = off_dev[:m]
         lin_off = off_dev[m:2 * m] if has_lin else None
@@ -198,10 +264,10 @@ class EmbedGather(torch.autograd.Function):
             dd = dd.contiguous() if dd is not None else None
             dl = dl.contiguous() if dl is not None else None
             nbytes = B * (4 * (m + nd) + 2 * 4 * m * D + 4 + 4 * m * (D + 1))
-            _lib.check(_run("embed_scatter_bwd[bytes]", nbytes, lambda: lib.xdfm_embed_scatter_bwd(
+            _lib.check(_run("embed_scatter_bwd[bytes]", nbytes, lambda: lib.xdfm_embed_scatter_bwd_marked(
                 _ptr(Xr), Xr.stride(0), B, _ptr(cols), _ptr(vocab), m, D, _ptr(dcols) if nd else None, nd,
-                _ptr(de), _ptr(dd), _ptr(dl), _ptr(flat), _ptr(tab_off), _ptr(lin_off), _ptr(d_w), _stream())),
-                "embed_scatter_bwd")
+                _ptr(de), _ptr(dd), _ptr(dl), _ptr(flat), _ptr(tab_off), _ptr(lin_off), _ptr(d_w), _ptr(marks),
+                _stream())), "embed_scatter_bwd")
         return grads, d_w
 
 
@@ -211,12 +277,13 @@ def apply_stashed_scatter(stash, dense_w, params=None):
     `dense_w`, the linear part's dense weight, directly."""
     with torch.no_grad():
         for (plan, X, d_emb, d_dnn, d_lin, has_lin, shapes, tables, need_w) in stash:
-            grads, d_w = EmbedGather.scatter(plan, X, d_emb, d_dnn, d_lin, has_lin, shapes, tables)
+            grads, d_w = EmbedGather.scatter(plan, X, d_emb, d_dnn, d_lin, has_lin, shapes, tables,
+                                             bool(need_w and dense_w is not None))
             owners = params if params is not None and len(params) == len(tables) else tables
             for t, g in zip(owners, grads):
                 t.grad = g
             if need_w and d_w is not None and dense_w is not None:
-                dense_w.grad = d_w.clone()
+                dense_w.grad = d_w if plan.arena_on else d_w.clone()
 
 
 # --------------------------------------------------------------------------------------------- #

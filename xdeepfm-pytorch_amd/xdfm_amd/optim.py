@@ -9,7 +9,10 @@ parameter, device-resident fp32 step counters) and hyper-parameters are torch's,
 
 The model's own train step may *arm* an L2 term for one step (`arm_l2`): K7 then adds 2*l2*w to the gradients
 while it streams the weights and returns the term's value (`l2_value`), which removes the regulariser's own
-passes over the parameters (basemodel.py:412-428) from the step."""
+passes over the parameters (basemodel.py:412-428) from the step.
+
+Gradients that are views of a kept gradient buffer (`ops.GradArena`, registered through `grad_sources`) are read by
+their chunk marks: K7 skips the untouched rows of the dense table gradients and re-zeroes the touched ones."""
 import ctypes
 
 import torch
@@ -23,6 +26,7 @@ class TableAdam(torch.optim.Adam):
         self._armed = None          # id(parameter) -> L2 strength, for the next step only
         self._desc = {}             # group index -> (key, ctypes array of xdfm_adam_tensor)
         self.l2_value = None        # [1] device tensor: value of the armed L2 term at the last step
+        self.grad_sources = []      # objects with .arenas() -> [ops.GradArena]: gradients K7 may read by their marks
 
     def owns(self, tensors):
         mine = {id(p) for g in self.param_groups for p in g["params"]}
@@ -85,8 +89,16 @@ class TableAdam(torch.optim.Adam):
                     arr[k].l2 = l2[k] if l2 is not None else 0.0
                 hit = self._desc[gi] = (key, arr)
             arr = hit[1]
+            arenas = [a for src in self.grad_sources for a in src.arenas() if a.pending]
             for k in range(T):
-                arr[k].grad = grads[k].data_ptr()
+                gp = grads[k].data_ptr()
+                arr[k].grad, arr[k].grad_marks = gp, None
+                for a in arenas:                       # a view of a kept gradient buffer: read it by its marks
+                    mp = a.marks_ptr(gp)
+                    if mp is not None and params[k].data_ptr() % 16 == 0:
+                        arr[k].grad_marks = mp
+                        a.consumed(gp)
+                        break
             torch._foreach_add_(steps, 1)
             dev = params[0].device
             ws = val = None
