@@ -24,6 +24,8 @@
  *
  * ABI 2 (this round): + cin_math option and f16x3 pack / workspace layouts, xdfm_cin_pack_all,
  * xdfm_cin_level_bwd_x_ex, xdfm_colsum, xdfm_head_fwd/bwd (K8), xdfm_adam_step (K7), xdfm_graph_node_census.
+ * ABI 3: + xdfm_embed_scatter_bwd_marked and xdfm_adam_tensor.grad_marks (gradient buffer kept across steps),
+ * xdfm_relu_bwd_colsum.
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -225,6 +227,11 @@ int xdfm_cin_pack_all(const xdfm_cin_pack_job* jobs, int L, void* stream);
  * g [rows][ld] fp32 (ld >= cols); ws: xdfm_colsum_ws_elems(cols) floats; out [cols]. */
 size_t xdfm_colsum_ws_elems(int cols);
 int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* out, void* stream);
+/* Backward of y = relu(x W^T + b) up to the GEMMs (deepctr/layers/core.py:120-134 with nn.ReLU, autograd's
+ * threshold_backward + the bias gradient): gz [rows][cols] = (y > 0) ? g : 0 and out [cols] = column sums of gz,
+ * fixed order; ws as for xdfm_colsum. */
+int xdfm_relu_bwd_colsum(const float* g, const float* y, long rows, int cols, long ldg, long ldy, float* ws, float* gz,
+                         float* out, void* stream);
 
 /* ------------------------------------------------------------------ output head of the binary task (K8)
  * z_b = lin_b + <u_b, wu> + <v_b, wv> + bias,  pred = sigmoid(z),  loss = sum_b BCE(pred_b, y_b).

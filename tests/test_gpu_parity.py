@@ -720,6 +720,30 @@ def test_train_step_keeps_table_gradients_clean_without_table_sized_fills():
         close(a, b.cpu().numpy(), rtol=2e-3, atol=2e-6, msg=k)
 
 
+def test_dense_relu_matches_linear_plus_relu():
+    """ops.DenseReLU (ReLU in the GEMM epilogue, mask + bias gradient in xdfm_relu_bwd_colsum) against
+    relu(F.linear) with autograd (deepctr/layers/core.py:120-134), incl. a ragged row count and zeros in y."""
+    from xdfm_amd import ops
+    dev = _dev()
+    torch.manual_seed(2)
+    for rows, k, n in ((4096, 429, 256), (100, 37, 70), (1, 8, 5)):
+        x = torch.randn(rows, k, device=dev)
+        W = torch.randn(n, k, device=dev) * 0.1
+        b = torch.randn(n, device=dev) * 0.1
+        g = torch.randn(rows, n, device=dev)
+        a = [t.clone().requires_grad_(True) for t in (x, W, b)]
+        r = [t.clone().double().requires_grad_(True) for t in (x, W, b)]
+        ya = ops.dense_relu(*a)
+        yr = torch.relu(torch.nn.functional.linear(*r))
+        ya.backward(g)
+        yr.backward(g.double())
+        close(ya, yr.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+        live = (yr.detach().abs() > 1e-4) | (yr.detach() == 0)          # away from the ReLU kink
+        assert bool(((ya.detach() > 0) == (yr.detach() > 0))[live].all())
+        for u, v, name in zip(a, r, "xWb"):
+            close(u.grad, v.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(v.grad.abs().max()), msg=name)
+
+
 def test_table_adam_kernel_matches_torch_adam():
     """K7 (xdfm_adam_step) behind xdfm_amd.optim.TableAdam against torch.optim.Adam(fused=True): same state
     layout and, over 6 steps with fresh dense gradients, the same parameters / moments to fp32 rounding, with

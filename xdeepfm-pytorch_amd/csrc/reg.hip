@@ -140,6 +140,29 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
         part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+// same walk with the ReLU mask applied on the way: gz = (y > 0) ? g : 0 is written out (the operand of the two
+// backward GEMMs of a dense layer) and summed (its bias gradient) -- threshold_backward + column sum in one pass
+__global__ __launch_bounds__(256) void relu_bwd_colsum_partial_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                                     long rows, int cols, long ldg, long ldy,
+                                                                     float* __restrict__ gz, float* __restrict__ part) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    const long per = (rows + CS_ROWBLK - 1) / CS_ROWBLK;
+    const long r0 = (long)blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
+    float a = 0.f;
+    if (c < cols)
+        for (long r = r0 + rg; r < r1; r += 4) {
+            const float v = y[r * ldy + c] > 0.f ? g[r * ldg + c] : 0.f;
+            gz[r * cols + c] = v;
+            a += v;
+        }
+    __shared__ float red[4][64];
+    red[rg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rg == 0 && c < cols)
+        part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // 64 columns per block, the CS_ROWBLK partials of a column summed by 4 threads in a fixed order
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int cols, float* __restrict__ out) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -166,6 +189,17 @@ int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* 
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 64), CS_ROWBLK), dim3(256), 0, st, g, rows, cols, ld, ws);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, st, ws, cols, out);
     return xdfm_check_launch("colsum");
+}
+
+int xdfm_relu_bwd_colsum(const float* g, const float* y, long rows, int cols, long ldg, long ldy, float* ws, float* gz,
+                         float* out, void* stream) {
+    XDFM_REQUIRE(g && y && ws && gz && out, "relu_bwd_colsum: null pointer");
+    XDFM_REQUIRE(rows > 0 && cols > 0 && ldg >= cols && ldy >= cols, "relu_bwd_colsum: bad shape rows=%ld cols=%d", rows, cols);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel, dim3(ceil_div(cols, 64), CS_ROWBLK), dim3(256), 0, st, g, y, rows, cols,
+                       ldg, ldy, gz, ws);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, st, ws, cols, out);
+    return xdfm_check_launch("relu_bwd_colsum");
 }
 
 }  // extern "C"

@@ -51,6 +51,7 @@ SIGNATURES = {
     "xdfm_adam_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
     "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
+    "xdfm_relu_bwd_colsum": (c_int, [P, P, c_long, c_int, c_long, c_long, P, P, P, P]),
     "xdfm_l2_reg_fwd": (c_int, [P, P, P, c_int, P, P, P]),
     "xdfm_l2_reg_bwd": (c_int, [P, P, P, c_int, P, P, P, c_int, P]),
 }

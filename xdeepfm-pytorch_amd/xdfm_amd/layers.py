@@ -228,6 +228,9 @@ class DNN(nn.Module):
 
     def forward(self, x):
         for i, lin in enumerate(self.linears):
+            if self.activation == "relu" and not self.use_bn:
+                x = self.dropout(ops.dense_relu(x, lin.weight, lin.bias))
+                continue
             x = ops.dense(x, lin.weight, lin.bias)
             if self.use_bn:
                 x = self.bn[i](x)
