@@ -336,13 +336,22 @@ class BaseModel(nn.Module):
         if plan.arena_on and plan not in self.optim.grad_sources:
             self.optim.grad_sources.append(plan)
 
+    def _unit_grad(self, loss):
+        """Root gradient of a backward pass, cached: autograd would otherwise fill a fresh ones tensor every step."""
+        key = (tuple(loss.shape), loss.device, loss.dtype)
+        hit = self.__dict__.get("_unit_grad_cache")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_unit_grad_cache"] = (key, torch.ones_like(loss))
+        return hit[1]
+
     def _split_step_first(self, x, y):
         self.optim.zero_grad()
         plan = self._gather_plan()
         plan.stash = []
         try:
             y_pred, loss = self._loss_forward(x, y)
-            (loss if self._aux_unset else loss + self.aux_loss).backward()
+            root = loss if self._aux_unset else loss + self.aux_loss
+            root.backward(self._unit_grad(root))
             stash = plan.stash
         finally:
             plan.stash = None
@@ -380,7 +389,7 @@ class BaseModel(nn.Module):
             # the term is identical on every replica and must count once)
             self.optim.arm_l2(*fuse)
             total_loss = loss if self._aux_unset else loss + self.aux_loss
-            total_loss.backward()
+            total_loss.backward(self._unit_grad(total_loss))
             if dp is not None:
                 dp.reduce_dense_grads(self)
         elif dp is None:

@@ -644,10 +644,13 @@ class Head(torch.autograd.Function):
         ctx.save_for_backward(pred, yv, u, wu, v, wv)
         ctx.cfg = (bias is not None, lin is not None, tuple(lin.shape) if lin is not None else None, Ku, Kv)
         ctx.mark_non_differentiable(pred)
+        ctx.set_materialize_grads(False)          # no [B] zero fill for pred's (unused) gradient slot
         return pred, loss
 
     @staticmethod
     def backward(ctx, _gpred, gloss):
+        if gloss is None:
+            return (None,) * 7
         lib = _lib.load()
         pred, yv, u, wu, v, wv = ctx.saved_tensors
         has_bias, has_lin, lin_shape, Ku, Kv = ctx.cfg
