@@ -4,8 +4,8 @@
 // rows j (row maxima by one reduction pass).  dOut is split once into fp16 hi / lo planes (it is the A
 // operand of every one of the K/32 column tiles); Z = xp*x0 is formed, scaled and split in registers.
 //
-//   pass 1  x3_rowmax_kernel      partial row maxima of dOut, x_prev, x0, then x3_rowscale_kernel -> scales
-//   pass 2  x3_split_dout_kernel  dOut * sD[h] -> planes [Hpad][NP/32][hi 32 | lo 32] fp16 (zero padded)
+//   pass 1  x3_rowmax_kernel      partial row maxima of dOut, x_prev, x0
+//   pass 2  x3_split_dout_kernel  partial maxima -> scales (header); dOut * sD[h] -> planes [Hpad][NP/32][hi 32 | lo 32] fp16 (zero padded)
 //   pass 3  cin_bwd_w_x3_kernel   MFMA; per n-split slabs (same tiling as the fp32 kernel)
 //   pass 4  x3_bww_unpack_kernel  ordered sum of the slabs, scales removed, [h][i*m+j] layout
 #include "xdfm_internal.h"
@@ -45,7 +45,7 @@ static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int H, int Hp, int m, long N) 
 // ---------------------------------------------------------------------------------------------
 // Row maxima without atomics or zero-initialised cells (nothing depends on a memset node inside a captured
 // graph): block (bx, row) stores the maximum of its X3_RM_COLS columns in parts[row*nbx + bx]; rows [0, H) are
-// dOut, [H, H+Hp) x_prev, [H+Hp, H+Hp+m) x0.  x3_rowscale_kernel reduces the partials to the power-of-two
+// dOut, [H, H+Hp) x_prev, [H+Hp, H+Hp+m) x0.  x3_split_dout_kernel reduces the partials to the power-of-two
 // scales hdr[0..Hpad) (dOut, < 2^15), hdr[Hpad..Hpad+IPAD) (x_prev, < 2^7), hdr[Hpad+IPAD..) (x0, < 2^7);
 // rows outside the matrices get scale 1.
 // hdr != NULL (only with gridDim.x == 1: one block covers a whole row): the block writes the row's scale itself
@@ -87,24 +87,37 @@ __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict_
     }
 }
 
-__global__ void x3_rowscale_kernel(const float* __restrict__ parts, int nbx, int H, int Hp, int m, int Hpad, int IPAD,
-                                   float* __restrict__ hdr) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= Hpad + IPAD + m) return;
-    int row = -1, target = 15;
-    if (t < Hpad) { if (t < H) row = t; }
-    else if (t < Hpad + IPAD) { target = 7; if (t - Hpad < Hp) row = H + (t - Hpad); }
-    else { target = 7; row = H + Hp + (t - Hpad - IPAD); }
-    float mx = 0.f;
-    if (row >= 0)
-        for (int k = 0; k < nbx; ++k) mx = fmaxf(mx, parts[(long)row * nbx + k]);
-    hdr[t] = x3w_pow2_scale(mx, target);
-}
-
 // one thread = 8 columns of one row: 128-B blocks [hi 32 halves | lo 32 halves] per 32 columns
+// parts != NULL: the scales are still partial maxima (x3_rowmax_kernel with several blocks per row).  Every block
+// then reduces its own row's nbx partials (uniform loads), and the blockIdx.x == 0 column of blocks also writes the
+// header -- its row's dOut scale, plus (thread t of block row r) entry r*256 + t of the x_prev / x0 scales -- for the
+// MFMA kernel and the unpack pass (no launch of its own for that).
 __global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restrict__ dOut, int H, long N, long NP,
-                                                           const float* __restrict__ hdr, char* __restrict__ planes) {
+                                                           float* __restrict__ hdr, char* __restrict__ planes,
+                                                           const float* __restrict__ parts, int nbx, int Hp, int m,
+                                                           int Hpad, int IPAD) {
     const int row = blockIdx.y;
+    float s_row = 1.f;
+    if (parts) {
+        if (row < H) {
+            float mx = 0.f;
+            for (int k = 0; k < nbx; ++k) mx = fmaxf(mx, parts[(long)row * nbx + k]);
+            s_row = x3w_pow2_scale(mx, 15);
+        }
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) hdr[row] = s_row;
+            const int e = row * 256 + threadIdx.x;               // entry of the x_prev | x0 part of the header
+            if (e < IPAD + m) {
+                const int src = e < IPAD ? (e < Hp ? H + e : -1) : H + Hp + (e - IPAD);
+                float mx = 0.f;
+                if (src >= 0)
+                    for (int k = 0; k < nbx; ++k) mx = fmaxf(mx, parts[(long)src * nbx + k]);
+                hdr[Hpad + e] = x3w_pow2_scale(mx, 7);
+            }
+        }
+    } else if (row < H) {
+        s_row = hdr[row];
+    }
     const long n = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
     if (n >= NP) return;
     float v[8];
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restr
     if (row < H) {
         // both float4 halves unconditionally from clamped addresses (N % 4 == 0, N >= 8 here), masked afterwards:
         // two loads in flight instead of one behind each condition
-        const float s = hdr[row];
+        const float s = s_row;
         const float* base = dOut + (long)row * N;
         const long n0c = n < N ? n : N - 4, n1c = n + 4 < N ? n + 4 : N - 4;
         const float4 a = *reinterpret_cast<const float4*>(base + n0c);
@@ -383,11 +396,12 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     } else {
         hipLaunchKernelGGL(x3_rowmax_kernel, dim3(w.nbx, H + Hp + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, N, parts,
                            (float*)nullptr, g.Hpad, g.IPAD);
-        hipLaunchKernelGGL(x3_rowscale_kernel, dim3(ceil_div(g.Hpad + g.IPAD + m, 256)), dim3(256), 0, st, parts, w.nbx, H,
-                           Hp, m, g.Hpad, g.IPAD, hdr);
     }
+    // several blocks per row: the split pass turns the partial maxima into the scales on its way (g.Hpad >= 128
+    // block rows x 256 threads cover the IPAD + m further header entries with room to spare)
+    XDFM_REQUIRE((long)g.Hpad * 256 >= g.IPAD + m, "cin_level_bwd_w: header larger than the split pass's grid");
     hipLaunchKernelGGL(x3_split_dout_kernel, dim3(ceil_div(w.NP, 2048), g.Hpad), dim3(256), 0, st, dOut, H, N, w.NP, hdr,
-                       planes);
+                       planes, w.nbx == 1 ? (const float*)nullptr : (const float*)parts, w.nbx, Hp, m, g.Hpad, g.IPAD);
     rc = xdfm_check_launch("cin_level_bwd_w split");
     if (rc) return rc;
     }
