@@ -14,6 +14,10 @@
 
 #define EMB_THREADS 256
 
+// Index arithmetic: no division by a run-time value sits in a loop (a v_div sequence is ~40 instructions; with one
+// per copied element the kernel was instruction-bound at 2.2 TB/s however large the batch).  Phase 0 also parks
+// everything later phases would otherwise fetch through dependent global loads -- row addresses, the dense
+// values of X, the dense weights -- in LDS, so that phases 1 and 2 issue independent loads / stores only.
 template <int VEC>
 __global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
     const float* __restrict__ X, long ldx, int B, const float* const* __restrict__ tables,
@@ -21,32 +25,74 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
     int m, int D, const int* __restrict__ dense_cols, const float* __restrict__ dense_w, int nd, int EB,
     float* __restrict__ emb_fm, float* __restrict__ dnn_in, float* __restrict__ lin_out, int* __restrict__ err_flag) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                          // [EB][m][D]
-    float* linv = smem + (size_t)EB * m * D;     // [EB][m]
+    float* tile = smem;                                                    // [EB][m][D]
+    float* linv = smem + (size_t)EB * m * D;                               // [EB][m]
+    const float** rowp = reinterpret_cast<const float**>(smem + ((((size_t)EB * m * (D + 1)) + 1) & ~(size_t)1));   // [EB][m]
+    float* densev = reinterpret_cast<float*>(rowp + (size_t)EB * m);       // [EB][nd]
+    float* wl = densev + (size_t)EB * nd;                                  // [nd]
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * EB;
     const int nb = (B - b0 < EB) ? B - b0 : EB;
     const int DV = D / VEC;
     const long N = (long)B * D;
 
-    // phase 0: the nb*m ids of the block -> LDS (clamped; out-of-range ids raise the flag), one load per thread
-    long* ids = reinterpret_cast<long*>(smem + ((((size_t)EB * m * (D + 1)) + 1) & ~(size_t)1));   // [EB][m], 8-byte aligned
-    for (int rj = tid; rj < nb * m; rj += EMB_THREADS) {
-        const int j = rj % m, bl = rj / m;
-        long id = (long)X[(long)(b0 + bl) * ldx + cols[j]];          // truncation, as Tensor.long() (basemodel.py:369)
-        const int V = vocab[j];
+    // phase 0a: dense values of the block's rows and the dense weights -> LDS (loads issued first, parked last)
+    const int ndense = nb * nd;
+    float dval[2] = {0.f, 0.f};
+    float wval = 0.f;
+    if (nd > 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int idx = tid + t * EMB_THREADS;
+            const int c = idx < ndense ? idx : 0;
+            const int bl = c / nd, k = c - bl * nd;
+            dval[t] = X[(long)(b0 + bl) * ldx + dense_cols[k]];
+        }
+        if (dense_w) wval = dense_w[tid < nd ? tid : 0];
+    }
+    // phase 0b: ids (clamped; out-of-range ids raise the flag) -> row addresses and linear-table values.
+    // m <= 32: lane & 31 is the field, 8 examples per pass; wider models take the division
+    const int npass = m <= 32 ? (nb + 7) / 8 : (nb * m + EMB_THREADS - 1) / EMB_THREADS;
+    for (int p = 0; p < npass; ++p) {
+        int jf, bl;
+        if (m <= 32) { jf = tid & 31; bl = (tid >> 5) + 8 * p; }
+        else { const int rj = tid + p * EMB_THREADS; bl = rj / m; jf = rj - bl * m; }
+        const bool live = jf < m && bl < nb;
+        const int jc = live ? jf : 0, bc = live ? bl : 0;
+        const float* tab = tables[jc];
+        const float* ltab = lin_tables ? lin_tables[jc] : tab;
+        const int V = vocab[jc];
+        long id = (long)X[(long)(b0 + bc) * ldx + cols[jc]];        // truncation, as Tensor.long() (basemodel.py:369)
         if (id < 0 || id >= V) {
-            if (err_flag) atomicOr(err_flag, 1);
+            if (err_flag && live) atomicOr(err_flag, 1);
             id = id < 0 ? 0 : V - 1;
         }
-        ids[rj] = id;
-        if (lin_tables) linv[rj] = lin_tables[j][id];
+        const float lv = ltab[lin_tables ? id : 0];
+        if (live) {
+            rowp[bl * m + jf] = tab + id * D;
+            if (lin_tables) linv[bl * m + jf] = lv;
+        }
+    }
+    if (nd > 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (tid + t * EMB_THREADS < ndense) densev[tid + t * EMB_THREADS] = dval[t];
+        for (int idx = tid + 2 * EMB_THREADS; idx < ndense; idx += EMB_THREADS) {       // > 512 dense values: rare
+            const int bl = idx / nd, k = idx - bl * nd;
+            densev[idx] = X[(long)(b0 + bl) * ldx + dense_cols[k]];
+        }
+        if (dense_w) {
+            if (tid < nd) wl[tid] = wval;
+            for (int k = tid + EMB_THREADS; k < nd; k += EMB_THREADS) wl[k] = dense_w[k];
+        }
     }
     __syncthreads();
     // phase 1: gather rows into the LDS tile (chunk = VEC floats of one row).  GB chunks per thread are loaded
     // back to back before any of them is stored, so a block pays about one HBM round trip for all its rows
-    // instead of one per loop iteration (the gather is latency-, not bandwidth-bound at 22 MB per batch).
+    // instead of one per loop iteration.
     const int nchunks = nb * m * DV;
+    const bool dv_pow2 = (DV & (DV - 1)) == 0;
+    const int dv_sh = 31 - __builtin_clz(DV);
     constexpr int GB = 8;
     for (int base = 0; base < nchunks; base += GB * EMB_THREADS) {
         float4 v[GB];
@@ -55,8 +101,9 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
         for (int k = 0; k < GB; ++k) {
             const int idx = base + k * EMB_THREADS + tid;
             const int cidx = idx < nchunks ? idx : nchunks - 1;
-            const int q = cidx % DV, rj = cidx / DV;
-            const float* src = tables[rj % m] + ids[rj] * D + q * VEC;
+            const int rj = dv_pow2 ? (cidx >> dv_sh) : (cidx / DV);
+            const int q = cidx - rj * DV;
+            const float* src = rowp[rj] + q * VEC;
             at[k] = idx < nchunks ? rj * D + q * VEC : -1;
             if constexpr (VEC == 4) {
                 v[k] = *reinterpret_cast<const float4*>(src);
@@ -78,26 +125,27 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
     }
     __syncthreads();
 
-    // phase 2a: dnn_in rows (sparse part is the tile verbatim, dense part copied from X)
+    // phase 2a: dnn_in rows (sparse part is the tile verbatim, dense part from the staged values)
     if (dnn_in) {
         const int ldd = m * D + nd;
         const int per = m * D;
-        for (int idx = tid; idx < nb * per; idx += EMB_THREADS) {
-            const int bl = idx / per, k = idx - bl * per;
-            dnn_in[(long)(b0 + bl) * ldd + k] = tile[idx];
-        }
-        for (int idx = tid; idx < nb * nd; idx += EMB_THREADS) {
-            const int bl = idx / nd, k = idx - bl * nd;
-            dnn_in[(long)(b0 + bl) * ldd + per + k] = X[(long)(b0 + bl) * ldx + dense_cols[k]];
+        for (int bl = 0; bl < nb; ++bl) {
+            float* drow = dnn_in + (long)(b0 + bl) * ldd;
+            const float* trow = tile + (size_t)bl * per;
+            for (int k = tid; k < per; k += EMB_THREADS) drow[k] = trow[k];
+            for (int k = tid; k < nd; k += EMB_THREADS) drow[per + k] = densev[bl * nd + k];
         }
     }
     // phase 2b: FM layout, field-major: for field j the nb*D floats of this block are contiguous
     {
         const int per = nb * D;
-        for (int idx = tid; idx < m * per; idx += EMB_THREADS) {
-            const int j = idx / per, k = idx - j * per;     // k = bl*D + d
-            const int bl = k / D, d = k - bl * D;
-            emb_fm[(long)j * N + (long)b0 * D + k] = tile[((size_t)bl * m + j) * D + d];
+        const bool d_pow2 = (D & (D - 1)) == 0;
+        const int d_sh = 31 - __builtin_clz(D);
+        for (int k = tid; k < per; k += EMB_THREADS) {
+            const int bl = d_pow2 ? (k >> d_sh) : (k / D);
+            const float* src = tile + (size_t)bl * m * D + (k - bl * D);
+            float* dst = emb_fm + (long)b0 * D + k;
+            for (int j = 0; j < m; ++j) dst[(long)j * N] = src[j * D];
         }
     }
     // phase 2c: linear logit, summed in field order then dense columns in column order
@@ -106,7 +154,7 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
         if (lin_tables)
             for (int j = 0; j < m; ++j) acc += linv[tid * m + j];
         float dacc = 0.f;
-        for (int k = 0; k < nd; ++k) dacc += X[(long)(b0 + tid) * ldx + dense_cols[k]] * dense_w[k];
+        for (int k = 0; k < nd; ++k) dacc += densev[tid * nd + k] * wl[k];
         lin_out[b0 + tid] = acc + dacc;
     }
 }
@@ -183,11 +231,15 @@ int xdfm_embed_gather_fwd(const float* X, long ldx, int B, const float* const* t
     // examples per block: tile <= 32 KiB, at most 16, at least 1
     int EB = (int)(8192 / ((long)m * D));
     if (EB > 16) EB = 16;
+    // A/B knob: 32 examples (2 KB runs per field, 3 workgroups per CU) measured 19 % slower at large batches
+    if (xdfm_opt(OPT_DBG) & 1024) { EB = (int)(16384 / ((long)m * D)); if (EB > 32) EB = 32; }
     if ((xdfm_opt(OPT_DBG) & 256) && EB > 4) EB = 4;      // A/B: more, smaller workgroups
     if ((xdfm_opt(OPT_DBG) & 512) && EB > 8) EB = 8;
     if (EB < 1) EB = 1;
-    // tile + linear values + ids (8 bytes each; the float part is kept even so that the ids are 8-byte aligned)
-    const size_t lds = ((size_t)EB * m * D + (size_t)EB * m) * sizeof(float) + (size_t)EB * m * sizeof(long) + 8;
+    // tile + linear values + row addresses (8 bytes each; the float part is kept even so that they are 8-byte
+    // aligned) + staged dense values and weights
+    const size_t lds = ((size_t)EB * m * D + (size_t)EB * m) * sizeof(float) + (size_t)EB * m * sizeof(void*) + 8 +
+                       ((size_t)EB * nd + (size_t)nd) * sizeof(float);
     XDFM_REQUIRE(lds <= 160 * 1024, "embed_gather_fwd: m*D=%ld too large for one LDS tile", (long)m * D);
     XDFM_REQUIRE(EB <= EMB_THREADS, "embed_gather_fwd: internal");
     dim3 grid(ceil_div(B, EB));
