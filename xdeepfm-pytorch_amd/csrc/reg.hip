@@ -132,7 +132,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     const long r0 = (long)blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
     float a = 0.f;
     if (c < cols)
-        for (long r = r0 + rg; r < r1; r += 4) a += g[r * ld + c];
+        for (long r = r0 + rg; r < r1; r += 16) {            // 4 rows per step, loads issued together
+            float gv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) gv[t] = g[(r + 4 * t < r1 ? r + 4 * t : r) * ld + c];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (r + 4 * t < r1) a += gv[t];
+        }
     __shared__ float red[4][64];
     red[rg][threadIdx.x & 63] = a;
     __syncthreads();
@@ -150,12 +157,25 @@ __global__ __launch_bounds__(256) void relu_bwd_colsum_partial_kernel(const floa
     const long per = (rows + CS_ROWBLK - 1) / CS_ROWBLK;
     const long r0 = (long)blockIdx.y * per, r1 = (r0 + per < rows) ? r0 + per : rows;
     float a = 0.f;
-    if (c < cols)
-        for (long r = r0 + rg; r < r1; r += 4) {
-            const float v = y[r * ldy + c] > 0.f ? g[r * ldg + c] : 0.f;
-            gz[r * cols + c] = v;
-            a += v;
+    if (c < cols) {
+        // 4 rows per step, both operands loaded unconditionally (a load behind the y > 0 test would wait for it)
+        for (long r = r0 + rg; r < r1; r += 16) {
+            float gv[4], yv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const long rr = r + 4 * t < r1 ? r + 4 * t : r;
+                gv[t] = g[rr * ldg + c];
+                yv[t] = y[rr * ldy + c];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (r + 4 * t >= r1) continue;
+                const float v = yv[t] > 0.f ? gv[t] : 0.f;
+                gz[(r + 4 * t) * cols + c] = v;
+                a += v;
+            }
         }
+    }
     __shared__ float red[4][64];
     red[rg][threadIdx.x & 63] = a;
     __syncthreads();
