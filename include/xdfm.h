@@ -109,11 +109,14 @@ int xdfm_embed_scatter_bwd(const float* X, long ldx, int B,
  * -- one byte per 16-byte chunk; d_dense_w must then point into d_flat too.  A caller that keeps d_flat across
  * steps hands the marks to K7 (xdfm_adam_tensor.grad_marks), which reads and re-zeroes only the marked chunks:
  * the table-sized zero fill of the gradients (optim.zero_grad over dense [V, D] gradients) and
- * the table-sized gradient read of the optimizer step both shrink to the rows the batch touched. */
+ * the table-sized gradient read of the optimizer step both shrink to the rows the batch touched.
+ * marks may be NULL.  ld_dnn / ld_lin: row strides (floats) of d_dnn_in and d_lin, 0 = dense (m*D + nd and 1):
+ * the row-parallel exchange hands over ONE gathered buffer whose rows hold [row gradients | X row | d_lin]. */
 int xdfm_embed_scatter_bwd_marked(const float* X, long ldx, int B,
                                   const int* cols, const int* vocab, int m, int D,
                                   const int* dense_cols, int nd,
-                                  const float* d_emb_fm, const float* d_dnn_in, const float* d_lin,
+                                  const float* d_emb_fm, const float* d_dnn_in, long ld_dnn,
+                                  const float* d_lin, long ld_lin,
                                   float* d_flat, const long* tab_off, const long* lin_off, float* d_dense_w,
                                   unsigned char* marks, void* stream);
 

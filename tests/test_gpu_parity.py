@@ -635,9 +635,13 @@ def test_marked_gradients_skip_untouched_rows_bit_exactly():
     P = lambda t: ctypes.c_void_p(t.data_ptr())
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     d_w = flat[offs[-1]:offs[-1] + nd]
-    _lib.check(lib.xdfm_embed_scatter_bwd_marked(P(X), X.stride(0), B, P(cols), P(voc), m, D, P(dcols), nd, P(d_emb),
-                                                 P(d_dnn), P(d_lin), P(flat), P(off_dev[:m]), P(off_dev[m:]), P(d_w),
-                                                 P(marks), st), "scatter marked")
+    # the strided form the row-parallel exchange uses: one buffer whose rows hold [d_dnn row | X row | d_lin]
+    packed = torch.cat([d_dnn, X, d_lin.view(B, 1)], 1).contiguous()
+    W_ = packed.shape[1]
+    Pv = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.check(lib.xdfm_embed_scatter_bwd_marked(Pv(packed[:, m * D + nd:]), W_, B, P(cols), P(voc), m, D, P(dcols), nd,
+                                                 P(d_emb), Pv(packed), W_, Pv(packed[:, W_ - 1]), W_, P(flat),
+                                                 P(off_dev[:m]), P(off_dev[m:]), P(d_w), P(marks), st), "scatter marked")
     plain = torch.zeros_like(flat)
     _lib.check(lib.xdfm_embed_scatter_bwd(P(X), X.stride(0), B, P(cols), P(voc), m, D, P(dcols), nd, P(d_emb), P(d_dnn),
                                           P(d_lin), P(plain), P(off_dev[:m]), P(off_dev[m:]),

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(
     const float* __restrict__ X, long ldx, int B, const int* __restrict__ cols, const int* __restrict__ vocab, int m,
     int D, int nd, const float* __restrict__ d_emb_fm, const float* __restrict__ d_dnn_in,
     const float* __restrict__ d_lin, float* __restrict__ d_flat, const long* __restrict__ tab_off,
-    const long* __restrict__ lin_off, unsigned char* __restrict__ marks) {
+    const long* __restrict__ lin_off, unsigned char* __restrict__ marks, long ld_dnn, long ld_lin) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)B * m * D;
     if (idx >= total) return;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(
     // both gradient sources are loaded unconditionally (a missing one aliases X and is masked): behind the two
     // conditions the loads were issued one after the other
     const float* pe = d_emb_fm ? d_emb_fm + ((long)j * B + b) * D + d : X;
-    const float* pd = d_dnn_in ? d_dnn_in + (long)b * ((long)m * D + nd) + (long)j * D + d : X;
+    const float* pd = d_dnn_in ? d_dnn_in + (long)b * ld_dnn + (long)j * D + d : X;
     const float ge = *pe, gd = *pd;
     const float g = (d_emb_fm ? ge : 0.f) + (d_dnn_in ? gd : 0.f);
     // marks: one byte per 16-byte chunk of d_flat, set where a gradient landed (several threads may store the
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(
     }
     if (d == 0 && d_lin && lin_off) {
         const long e = lin_off[j] + id;
-        atomicAdd(d_flat + e, d_lin[b]);
+        atomicAdd(d_flat + e, d_lin[(long)b * ld_lin]);
         if (marks) marks[e >> 2] = 1;
     }
 }
@@ -201,12 +201,13 @@ __global__ __launch_bounds__(256) void dense_w_grad_kernel(const float* __restri
                                                           const int* __restrict__ dense_cols, int nd,
                                                           const float* __restrict__ d_lin,
                                                           float* __restrict__ d_dense_w,
-                                                          unsigned char* __restrict__ marks, long mark_base) {
+                                                          unsigned char* __restrict__ marks, long mark_base,
+                                                          long ld_lin) {
     const int k = blockIdx.y;
     const int col = dense_cols[k];
     float part = 0.f;
     for (long b = (long)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (long)gridDim.x * blockDim.x)
-        part += X[b * ldx + col] * d_lin[b];
+        part += X[b * ldx + col] * d_lin[b * ld_lin];
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     __shared__ float wsum[4];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
@@ -258,15 +259,18 @@ int xdfm_embed_scatter_bwd(const float* X, long ldx, int B, const int* cols, con
                            const int* dense_cols, int nd, const float* d_emb_fm, const float* d_dnn_in,
                            const float* d_lin, float* d_flat, const long* tab_off, const long* lin_off,
                            float* d_dense_w, void* stream) {
-    return xdfm_embed_scatter_bwd_marked(X, ldx, B, cols, vocab, m, D, dense_cols, nd, d_emb_fm, d_dnn_in, d_lin, d_flat,
-                                         tab_off, lin_off, d_dense_w, nullptr, stream);
+    return xdfm_embed_scatter_bwd_marked(X, ldx, B, cols, vocab, m, D, dense_cols, nd, d_emb_fm, d_dnn_in, 0, d_lin, 0,
+                                         d_flat, tab_off, lin_off, d_dense_w, nullptr, stream);
 }
 
 int xdfm_embed_scatter_bwd_marked(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
                                   const int* dense_cols, int nd, const float* d_emb_fm, const float* d_dnn_in,
-                                  const float* d_lin, float* d_flat, const long* tab_off, const long* lin_off,
-                                  float* d_dense_w, unsigned char* marks, void* stream) {
+                                  long ld_dnn, const float* d_lin, long ld_lin, float* d_flat, const long* tab_off,
+                                  const long* lin_off, float* d_dense_w, unsigned char* marks, void* stream) {
     XDFM_REQUIRE(X && cols && vocab, "embed_scatter_bwd: null pointer");
+    if (ld_dnn <= 0) ld_dnn = (long)m * D + nd;
+    if (ld_lin <= 0) ld_lin = 1;
+    XDFM_REQUIRE(ld_dnn >= (long)m * D, "embed_scatter_bwd: ld_dnn %ld smaller than m*D", ld_dnn);
     XDFM_REQUIRE(!marks || (d_flat && (((size_t)d_flat) & 15) == 0), "embed_scatter_bwd: marks need a 16-byte aligned d_flat");
     XDFM_REQUIRE(!marks || !d_dense_w || d_dense_w >= d_flat, "embed_scatter_bwd: with marks d_dense_w must lie inside d_flat");
     XDFM_REQUIRE(d_flat || (!tab_off && !lin_off), "embed_scatter_bwd: offsets without a gradient buffer");
@@ -275,7 +279,7 @@ int xdfm_embed_scatter_bwd_marked(const float* X, long ldx, int B, const int* co
     if (tab_off || (d_lin && lin_off)) {
         const long total = (long)B * m * D;
         hipLaunchKernelGGL(embed_scatter_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, X, ldx, B, cols, vocab,
-                           m, D, nd, d_emb_fm, d_dnn_in, d_lin, d_flat, tab_off, lin_off, marks);
+                           m, D, nd, d_emb_fm, d_dnn_in, d_lin, d_flat, tab_off, lin_off, marks, ld_dnn, ld_lin);
         int rc = xdfm_check_launch("embed_scatter_bwd");
         if (rc) return rc;
     }
@@ -284,7 +288,7 @@ int xdfm_embed_scatter_bwd_marked(const float* X, long ldx, int B, const int* co
         int gx = ceil_div(B, 256);
         if (gx > 64) gx = 64;
         hipLaunchKernelGGL(dense_w_grad_kernel, dim3(gx, nd), dim3(256), 0, st, X, ldx, B, dense_cols, nd, d_lin,
-                           d_dense_w, marks, marks ? (long)(d_dense_w - d_flat) : 0L);
+                           d_dense_w, marks, marks ? (long)(d_dense_w - d_flat) : 0L, ld_lin);
         return xdfm_check_launch("embed_scatter_bwd dense_w");
     }
     return XDFM_OK;

@@ -26,7 +26,8 @@ SIGNATURES = {
     "xdfm_graph_node_census": (c_int, [P, P, P, P]),
     "xdfm_embed_gather_fwd": (c_int, [P, c_long, c_int, P, P, P, P, c_int, c_int, P, P, c_int, P, P, P, P, P]),
     "xdfm_embed_scatter_bwd": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P]),
-    "xdfm_embed_scatter_bwd_marked": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P]),
+    "xdfm_embed_scatter_bwd_marked": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, c_long, P, c_long,
+                                              P, P, P, P, P, P]),
     "xdfm_cin_fwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_fwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "xdfm_cin_pack_all_supported": (c_int, [c_int, c_int, c_int]),

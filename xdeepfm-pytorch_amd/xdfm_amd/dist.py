@@ -10,9 +10,10 @@ identical:
 
   * dense weights (CIN, DNN, heads, attention: a few MB): ONE flat all-reduce SUM;
   * embedding tables: never all-reduced as dense [V, D] tensors.  The per-rank row gradients
-    (B_local x m x (D+1) floats, about 7.7 MB at B=4096, m=26, D=16) are all-gathered and every
-    rank runs the same scatter over all ranks' rows in rank order, so the dense table gradients
-    come out identical everywhere without moving table-sized data over the point-to-point links;
+    (B_local x (m x D + X row + 1) floats, 7.7 MB at B=4096, m=26, D=16) are all-gathered in ONE
+    collective and every rank runs the same single scatter launch over all ranks' rows, so the
+    dense table gradients come out identical everywhere without moving table-sized data over the
+    point-to-point links;
   * the L2 gradient is applied locally after the reduce (it is the same on every replica).
 """
 import torch
@@ -117,24 +118,59 @@ class RowParallel(object):
             g.copy_(flat[off:off + n].view_as(g))
             off += n
 
-    def exchange_rows(self, X, d_emb, d_dnn, d_lin):
-        """All-gather the inputs of the embedding scatter; returns one (X, d_emb, d_dnn, d_lin) per
-        rank, in rank order, so every rank accumulates the same rows in the same order."""
-        sizes = self.local_sizes()
-        if X.shape[0] != sizes[self.rank]:
-            raise RuntimeError("exchange_rows: local batch %d does not match the sharded size %d"
-                               % (X.shape[0], sizes[self.rank]))
-        m = d_emb.shape[0]
-        B = X.shape[0]
-        D = d_emb.shape[1] // max(B, 1)
-        Xs = self.all_gather_padded(X, sizes)
-        # FM layout [m, B*D] -> rows-major [B, m*D] for the variable-size gather, and back
-        e = d_emb.view(m, B, D).permute(1, 0, 2).reshape(B, m * D)
-        es = self.all_gather_padded(e, sizes)
-        ds = self.all_gather_padded(d_dnn, sizes)
-        ls = self.all_gather_padded(d_lin, sizes)
-        out = []
-        for r in range(self.world):
-            er = es[r].view(sizes[r], m, D).permute(1, 0, 2).reshape(m, sizes[r] * D).contiguous()
-            out.append((Xs[r], er, ds[r], ls[r]))
+    def all_gather_rows(self, t):
+        """[rows, C] on every rank (same shape everywhere) -> [world * rows, C], rank-major."""
+        t = t.contiguous()
+        if self._via_host(t) or self.backend == "gloo":
+            src = t.cpu() if t.is_cuda else t
+            outs = [torch.empty_like(src) for _ in range(self.world)]
+            dist.all_gather(outs, src, group=self.group)
+            return torch.cat(outs, dim=0).to(t.device)
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t, group=self.group)
         return out
+
+    def exchange_rows(self, X, d_emb, d_dnn, d_lin):
+        """All-gather the inputs of the embedding scatter with ONE collective.
+
+        Each rank packs a [rows, m*D + ncols + 1] buffer -- per example: the row gradients of its m embedding rows
+        (the CIN's and the DNN's contributions already summed: that halves the volume), its row of X (ids and dense
+        values) and its linear-logit gradient -- 1.9 KB per example at config 2.  Ranks with fewer rows (ragged last
+        batch) pad with zero rows, which scatter exact zeros.  The gathered buffer is handed to the scatter as
+        strided views, so every rank runs ONE scatter launch over all ranks' rows in rank order; no transposes, no
+        per-rank launches.  Returns [(X, None, row_grads, d_lin)] for EmbedGather.scatter."""
+        sizes = self.local_sizes()
+        B = X.shape[0]
+        if B != sizes[self.rank]:
+            raise RuntimeError("exchange_rows: local batch %d does not match the sharded size %d" % (B, sizes[self.rank]))
+        if d_emb is None and d_dnn is None:
+            raise RuntimeError("exchange_rows: no row gradients to exchange")
+        ncols = X.shape[1]
+        if d_emb is not None:
+            m = d_emb.shape[0]
+            D = d_emb.shape[1] // max(B, 1)
+            mD = m * D
+        else:
+            mD = None
+        rows = max(sizes)
+        if mD is None:
+            # without the FM-layout gradient the width of the sparse part is not known here: ship d_dnn whole
+            mD = d_dnn.shape[1]
+        Q = torch.empty((rows, mD + ncols + 1), dtype=torch.float32, device=X.device)
+        if rows > B:
+            Q[B:].zero_()
+        if d_emb is not None:
+            e = d_emb.view(m, B, D).permute(1, 0, 2)
+            if d_dnn is not None:
+                torch.add(d_dnn[:, :mD].view(B, m, D), e, out=Q[:B, :mD].view(B, m, D))
+            else:
+                Q[:B, :mD].view(B, m, D).copy_(e)
+        else:
+            Q[:B, :mD].copy_(d_dnn[:, :mD])
+        Q[:B, mD:mD + ncols].copy_(X)
+        if d_lin is not None:
+            Q[:B, mD + ncols].copy_(d_lin.reshape(B))
+        else:
+            Q[:B, mD + ncols].zero_()
+        G = self.all_gather_rows(Q)
+        return [(G[:, mD:mD + ncols], None, G[:, :mD], G[:, mD + ncols])]

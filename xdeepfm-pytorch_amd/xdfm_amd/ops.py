@@ -260,14 +260,18 @@ class EmbedGather(torch.autograd.Function):
             pieces = plan.dp.exchange_rows(X, d_emb, d_dnn, d_lin)
         for (Xr, de, dd, dl) in pieces:
             B = Xr.shape[0]
+            # the exchange hands over strided views of one gathered buffer: rows may be wider than their payload
             de = de.contiguous() if de is not None else None
-            dd = dd.contiguous() if dd is not None else None
-            dl = dl.contiguous() if dl is not None else None
+            if dd is not None and dd.stride(-1) != 1:
+                dd = dd.contiguous()
+            dl = dl.reshape(B) if dl is not None else None
+            ld_dnn = dd.stride(0) if dd is not None else 0
+            ld_lin = dl.stride(0) if dl is not None and B > 1 else (1 if dl is not None else 0)
             nbytes = B * (4 * (m + nd) + 2 * 4 * m * D + 4 + 4 * m * (D + 1))
             _lib.check(_run("embed_scatter_bwd[bytes]", nbytes, lambda: lib.xdfm_embed_scatter_bwd_marked(
                 _ptr(Xr), Xr.stride(0), B, _ptr(cols), _ptr(vocab), m, D, _ptr(dcols) if nd else None, nd,
-                _ptr(de), _ptr(dd), _ptr(dl), _ptr(flat), _ptr(tab_off), _ptr(lin_off), _ptr(d_w), _ptr(marks),
-                _stream())), "embed_scatter_bwd")
+                _ptr(de), _ptr(dd), ld_dnn, _ptr(dl), ld_lin, _ptr(flat), _ptr(tab_off), _ptr(lin_off), _ptr(d_w),
+                _ptr(marks), _stream())), "embed_scatter_bwd")
         return grads, d_w
 
 
