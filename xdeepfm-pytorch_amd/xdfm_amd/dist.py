@@ -112,11 +112,12 @@ class RowParallel(object):
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
         self.all_reduce_sum(flat)
-        off = 0
+        views, off = [], 0
         for g in grads:
             n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+            views.append(flat[off:off + n].view_as(g))
             off += n
+        torch._foreach_copy_(grads, views)            # one multi-tensor launch instead of one copy per gradient
 
     def all_gather_rows(self, t):
         """[rows, C] on every rank (same shape everywhere) -> [world * rows, C], rank-major."""
