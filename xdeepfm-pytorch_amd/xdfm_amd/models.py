@@ -552,11 +552,13 @@ class BaseModel(nn.Module):
         self.stop_training = False
         print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
             sample_num, len(val_y), steps_per_epoch))
+        loss_log = None
         for epoch in range(initial_epoch, epochs):
             cbs.on_epoch_begin(epoch)
             epoch_logs, train_result = {}, {}
             t_epoch = time.time()
             total_loss_epoch = 0.0
+            step_no = 0
             order = epoch_order(sample_num, shuffle)
             if order is not None:
                 order = order.to(X_all.device)
@@ -571,10 +573,14 @@ class BaseModel(nn.Module):
                     xd = xb.to(self.device)
                     yd = yb.to(self.device)
                     y_pred, loss, total_loss = self.train_on_batch(xd, yd)
-                    if dp is None:
-                        total_loss_epoch += total_loss.item()
-                    else:
-                        total_loss_epoch += dp.sum_scalar(loss.detach()) + (total_loss - loss.detach()).item()
+                    # The reference reads the loss back every step (`total_loss.item()`, basemodel.py:262): a host
+                    # sync per step that leaves the GPU idle while the next step is being enqueued.  The values are
+                    # parked on the device instead and read once per epoch, summed in the same order in double.
+                    if loss_log is None or loss_log.device != total_loss.device:
+                        loss_log = torch.empty((steps_per_epoch + 1, 2), dtype=torch.float32, device=total_loss.device)
+                    loss_log[step_no, 0:1].copy_(loss.detach().reshape(1))
+                    loss_log[step_no, 1:2].copy_(total_loss.detach().reshape(1))
+                    step_no += 1
                     if verbose > 0:
                         yt, yp = yd, y_pred
                         if dp is not None:
@@ -588,6 +594,16 @@ class BaseModel(nn.Module):
                 raise
             if bar is not None:
                 bar.close()
+            if step_no:
+                data_l, total_l = loss_log[:step_no, 0], loss_log[:step_no, 1]
+                if dp is not None:
+                    # the data loss is a SUM over the global batch; the L2 part (total - data) is the same on every rank
+                    data_sum = dp.all_reduce_sum(data_l.clone())
+                    vals = [a + (t - d) for a, t, d in zip(data_sum.tolist(), total_l.tolist(), data_l.tolist())]
+                else:
+                    vals = total_l.tolist()
+                for v in vals:
+                    total_loss_epoch += v
             epoch_logs["loss"] = total_loss_epoch / sample_num
             for name, vals in train_result.items():
                 epoch_logs[name] = np.sum(vals) / steps_per_epoch

@@ -234,7 +234,7 @@ class EmbedGather(torch.autograd.Function):
         # starts as zeros, or -- when L2Reg.backward deferred the tables' L2 term to us -- as
         # 2*l2*gscale*w, which saves a memset, a table-sized temporary and one add per table.
         defer, plan.reg_defer = plan.reg_defer, None
-        arena = plan.arena(shapes, dev) if defer is None and all(t.grad is None for t in tables) else None
+        arena = plan.arena(shapes, dev) if plan.arena_on and defer is None and all(t.grad is None for t in tables) else None
         marks = None
         if arena is not None:
             arena.begin()
