@@ -79,6 +79,28 @@ def test_metrics_vs_sklearn_golden():
         M.roc_auc_score(np.ones(4), np.arange(4))
 
 
+def test_device_metrics_equal_the_numpy_metrics():
+    """xdfm_amd.metrics.*_device (what `fit` logs per step without a host sync) against the numpy versions that are
+    pinned to sklearn above: AUC bit for bit (ties, repeated scores, tiny batches), logloss / mse to 1e-12; a
+    single-class batch gives NaN where the host version raises."""
+    import torch
+    from xdfm_amd import metrics as M
+    rng = np.random.default_rng(7)
+    for n, ties in ((4096, False), (4096, True), (100, True), (2, False)):
+        y = (rng.random(n) < 0.3).astype(np.float32)
+        y[0], y[-1] = 1.0, 0.0
+        p = rng.random(n).astype(np.float32)
+        if ties:
+            p = np.round(p * 20) / 20                      # many equal scores, incl. 0 and 1
+        yt, pt = torch.from_numpy(y), torch.from_numpy(p)
+        assert float(M.roc_auc_score_device(yt, pt)) == M.roc_auc_score(y, p.astype(np.float64))
+        assert abs(float(M.log_loss_device(yt, pt)) - M.log_loss(y, p.astype(np.float64))) < 1e-12
+        assert abs(float(M.mean_squared_error_device(yt, pt)) - M.mean_squared_error(y, p.astype(np.float64))) < 1e-12
+    ones = torch.ones(8)
+    assert torch.isnan(M.roc_auc_score_device(ones, torch.rand(8)))
+    assert set(M.DEVICE) == {M.log_loss, M.roc_auc_score, M.mean_squared_error}
+
+
 def test_callbacks_keras_semantics(tmp_path):
     from deepctr.callbacks import CallbackList, EarlyStopping, History, ModelCheckpoint
 

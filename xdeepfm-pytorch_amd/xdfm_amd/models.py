@@ -552,13 +552,14 @@ class BaseModel(nn.Module):
         self.stop_training = False
         print("Train on {0} samples, validate on {1} samples, {2} steps per epoch".format(
             sample_num, len(val_y), steps_per_epoch))
-        loss_log = None
+        loss_log = metric_log = None
         for epoch in range(initial_epoch, epochs):
             cbs.on_epoch_begin(epoch)
             epoch_logs, train_result = {}, {}
             t_epoch = time.time()
             total_loss_epoch = 0.0
             step_no = 0
+            logged = {}
             order = epoch_order(sample_num, shuffle)
             if order is not None:
                 order = order.to(X_all.device)
@@ -585,9 +586,18 @@ class BaseModel(nn.Module):
                         yt, yp = yd, y_pred
                         if dp is not None:
                             yt, yp = dp.gather_rows(yd.reshape(-1)), dp.gather_rows(y_pred.detach().reshape(-1))
-                        for name, fn in self.metrics.items():
-                            train_result.setdefault(name, []).append(
-                                fn(yt.cpu().data.numpy(), yp.cpu().data.numpy().astype("float64")))
+                        for k, (name, fn) in enumerate(self.metrics.items()):
+                            dev_fn = M.DEVICE.get(fn) if yt.is_cuda else None
+                            if dev_fn is None:
+                                train_result.setdefault(name, []).append(
+                                    fn(yt.cpu().data.numpy(), yp.cpu().data.numpy().astype("float64")))
+                                continue
+                            # same metric on the device, parked beside the losses and read once per epoch
+                            if metric_log is None or metric_log.device != yt.device:
+                                metric_log = torch.empty((steps_per_epoch + 1, max(len(self.metrics), 1)),
+                                                         dtype=torch.float64, device=yt.device)
+                            metric_log[step_no - 1, k:k + 1].copy_(dev_fn(yt, yp.detach()).reshape(1))
+                            logged[name] = k
             except KeyboardInterrupt:
                 if bar is not None:
                     bar.close()
@@ -605,8 +615,14 @@ class BaseModel(nn.Module):
                 for v in vals:
                     total_loss_epoch += v
             epoch_logs["loss"] = total_loss_epoch / sample_num
-            for name, vals in train_result.items():
-                epoch_logs[name] = np.sum(vals) / steps_per_epoch
+            for name, k in logged.items():
+                vals = metric_log[:step_no, k].tolist()
+                if name == "auc" and any(v != v for v in vals):
+                    raise ValueError("Only one class present in y_true. ROC AUC score is not defined in that case.")
+                train_result[name] = vals
+            for name in self.metrics:                              # History keys in the order `compile` was given
+                if name in train_result:
+                    epoch_logs[name] = np.sum(train_result[name]) / steps_per_epoch
             if do_validation:
                 for name, val in self.evaluate(val_x, val_y, batch_size).items():
                     epoch_logs["val_" + name] = val
