@@ -748,6 +748,54 @@ def test_dense_relu_matches_linear_plus_relu():
             close(u.grad, v.grad.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(v.grad.abs().max()), msg=name)
 
 
+def test_user_driven_loop_gets_plain_dense_table_gradients():
+    """The kept gradient buffer is an internal of the model's own train step.  Code that drives autograd itself --
+    here: two backward passes over different batches accumulated without zero_grad, then an edit of .grad -- must
+    see ordinary dense gradients (not views of the kept buffer) so that TableAdam.step() honours everything such
+    code put into them."""
+    import torch.nn.functional as F
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    vocab, nd, D = [50, 31, 77, 12, 9, 40], 3, 8
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(nd)]
+    model = xDeepFM(cols, cols, dnn_hidden_units=(32, 16), cin_layer_size=(16, 8), l2_reg_dnn=1e-5, device=dev)
+    model.compile("adam", "binary_crossentropy", metrics=[])
+    model.train()
+    batches = [orc.synthetic_batch(128, vocab, nd, seed=700 + s) for s in range(3)]
+    X0, y0 = batches[0]
+    model.train_on_batch(T(X0).to(dev), T(y0).to(dev))            # own step: the kept buffer is in use and clean again
+    arena, = model._plan.arenas()
+    assert not arena.pending and not model._plan.arena_on
+    lo, hi = arena.base, arena.base + arena.nbytes
+
+    def backward(k):
+        X, y = batches[k]
+        pred = model(T(X).to(dev))
+        F.binary_cross_entropy(pred.squeeze(), T(y).to(dev).squeeze(), reduction="sum").backward()
+
+    tables = [model.embedding_dict["C%d" % (i + 1)].weight for i in range(len(vocab))]
+    single = []
+    for k in (1, 2):
+        model.optim.zero_grad()
+        backward(k)
+        assert all(not (lo <= t.grad.data_ptr() < hi) for t in tables) and not arena.pending
+        single.append([t.grad.clone() for t in tables])
+    model.optim.zero_grad()
+    backward(1)
+    backward(2)                                                   # accumulates into the existing .grad
+    for t, a, b in zip(tables, single[0], single[1]):
+        close(t.grad, (a + b).cpu().numpy(), rtol=1e-4, atol=1e-6)
+    before = [t.detach().clone() for t in tables]
+    for t in tables:
+        t.grad.add_(1e-3)                                         # e.g. a hand-written regulariser: touches EVERY row
+    model.optim.step()
+    for t, b in zip(tables, before):
+        assert bool(((t.detach() - b).abs() > 0).all())           # every row moved: nothing was skipped by marks
+    assert not arena.pending and float(arena.flat.abs().max()) == 0.0
+
+
 def test_table_adam_kernel_matches_torch_adam():
     """K7 (xdfm_adam_step) behind xdfm_amd.optim.TableAdam against torch.optim.Adam(fused=True): same state
     layout and, over 6 steps with fresh dense gradients, the same parameters / moments to fp32 rounding, with

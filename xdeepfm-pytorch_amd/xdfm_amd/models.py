@@ -10,6 +10,7 @@ and linear logit together), the CIN stack on MFMA kernels, and a handful of tiny
 torch.distributed initialised (one process per GPU, RCCL) `fit` shards every global batch row-wise
 over the ranks (xdfm_amd/dist.py).
 """
+import contextlib
 import time
 
 import numpy as np
@@ -330,11 +331,27 @@ class BaseModel(nn.Module):
     # row gradients of the gather) contains no collective, so it can be replayed from a HIP graph; the second
     # exchanges the rows, scatters, all-reduces the dense gradients and runs the optimizer, eagerly.
     def _use_grad_arena(self, plan):
-        """Keep the dense table gradients across steps when the optimizer can consume them by their marks."""
+        """Keep the dense table gradients across steps when the optimizer can consume them by their marks -- inside the
+        model's OWN train step only (`_own_step`): there nothing touches a gradient between the scatter and K7.  A
+        user-driven loop (model(x); loss.backward(); edit .grad; optim.step()) gets ordinary dense gradients, because
+        K7 would not see what such code adds outside the marked chunks."""
         from .optim import TableAdam
-        plan.arena_on = isinstance(getattr(self, "optim", None), TableAdam)
+        plan.arena_on = bool(self.__dict__.get("_own_step")) and isinstance(getattr(self, "optim", None), TableAdam)
         if plan.arena_on and plan not in self.optim.grad_sources:
             self.optim.grad_sources.append(plan)
+
+    @contextlib.contextmanager
+    def _own_step_scope(self):
+        prev = self.__dict__.get("_own_step", False)
+        self.__dict__["_own_step"] = True
+        if self._plan is not None:
+            self._use_grad_arena(self._plan)
+        try:
+            yield
+        finally:
+            self.__dict__["_own_step"] = prev
+            if self._plan is not None and not prev:
+                self._plan.arena_on = False
 
     def _unit_grad(self, loss):
         """Root gradient of a backward pass, cached: autograd would otherwise fill a fresh ones tensor every step."""
@@ -345,6 +362,10 @@ class BaseModel(nn.Module):
         return hit[1]
 
     def _split_step_first(self, x, y):
+        with self._own_step_scope():
+            return self._split_step_first_body(x, y)
+
+    def _split_step_first_body(self, x, y):
         self.optim.zero_grad()
         plan = self._gather_plan()
         plan.stash = []
@@ -358,6 +379,10 @@ class BaseModel(nn.Module):
         return y_pred.detach(), loss.detach(), stash
 
     def _split_step_second(self, y_pred, loss, stash, fuse):
+        with self._own_step_scope():
+            return self._split_step_second_body(y_pred, loss, stash, fuse)
+
+    def _split_step_second_body(self, y_pred, loss, stash, fuse):
         dp = xdist.current()
         dense_w = self.linear_model.weight if getattr(self.linear_model, "dense_feature_columns", None) else None
         ops.apply_stashed_scatter(stash, dense_w, self._gather_tables())
@@ -377,6 +402,10 @@ class BaseModel(nn.Module):
         return bool(getattr(self, "_fused_linear", False))
 
     def _train_step_eager(self, x, y):
+        with self._own_step_scope():
+            return self._train_step_eager_body(x, y)
+
+    def _train_step_eager_body(self, x, y):
         dp = xdist.current()
         fuse = self._l2_fusion()
         if self._can_split_step(dp, fuse):
