@@ -139,8 +139,10 @@ class GradArena:
     (`xdfm_embed_scatter_bwd_marked`), K7 reads only marked chunks and writes zeros back (`xdfm_adam_tensor.grad_marks`),
     so the buffer is clean again when the step ends.  `pending` = byte offsets of the views handed to autograd that
     no optimizer step has consumed yet; a scatter that finds leftovers (a step without K7, a gradient that autograd
-    copied instead of adopting) clears everything the slow way first -- correctness never depends on the fast path.
-    Consequence worth knowing: after `optim.step()` the tables' `.grad` read zeros (they are views of this buffer)."""
+    copied instead of adopting) clears everything the slow way first.  `EmbedPlan.arena_on` is raised by the model's
+    own train step only (models.py::_own_step_scope): K7 never sees what other code adds to a gradient outside the
+    marked chunks, so user-driven autograd loops get ordinary dense gradients.  Consequence worth knowing: after the
+    model's own step the tables' `.grad` read zeros (they are views of this buffer)."""
 
     def __init__(self, numel, device):
         self.flat = torch.zeros(numel, dtype=torch.float32, device=device)
