@@ -16,6 +16,9 @@
 // two table-sized passes per step (sum of squares; gradient initialisation) from the train step.
 #include "xdfm_internal.h"
 
+#include <algorithm>
+#include <vector>
+
 #define ADAM_THREADS 256
 #define ADAM_BX 128
 
@@ -178,15 +181,24 @@ int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double bet
                                                   ((size_t)tensors[t].exp_avg_sq)) & 15) == 0,
                      "adam_step: tensor %d has grad_marks but a pointer that is not 16-byte aligned", t);
     hipStream_t st = (hipStream_t)stream;
-    for (int t0 = 0; t0 < T; t0 += ADAM_CHUNK) {
+    // Launch composition: tensors sorted by size and dealt round-robin to the launches, so that every launch streams
+    // its share of the big tables and the small tensors' latency-bound blocks run underneath (a launch of small
+    // tensors alone took 25 us for 30 MB).  The order is a pure function of the sizes: deterministic.
+    const int nlaunch = ceil_div(T, ADAM_CHUNK);
+    std::vector<int> order(T);
+    for (int t = 0; t < T; ++t) order[t] = t;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tensors[a].numel > tensors[b].numel; });
+    int slot0 = 0;
+    for (int l = 0; l < nlaunch; ++l) {
         AdamBatch batch;
-        const int cnt = T - t0 < ADAM_CHUNK ? T - t0 : ADAM_CHUNK;
-        for (int k = 0; k < cnt; ++k) batch.t[k] = tensors[t0 + k];
-        for (int k = cnt; k < ADAM_CHUNK; ++k) batch.t[k] = tensors[t0];
+        int cnt = 0;
+        for (int k = l; k < T; k += nlaunch) batch.t[cnt++] = tensors[order[k]];
+        for (int k = cnt; k < ADAM_CHUNK; ++k) batch.t[k] = batch.t[0];
         int bx = xdfm_opt(OPT_ADAM_BX);
         if (bx <= 0 || bx > ADAM_BX) bx = ADAM_BX;
-        hipLaunchKernelGGL(adam_step_kernel, dim3(bx, cnt), dim3(ADAM_THREADS), 0, st, batch, t0, lr, beta1, beta2, eps,
+        hipLaunchKernelGGL(adam_step_kernel, dim3(bx, cnt), dim3(ADAM_THREADS), 0, st, batch, slot0, lr, beta1, beta2, eps,
                            l2_value ? l2_ws : nullptr);
+        slot0 += cnt;
     }
     if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(1024), 0, st, l2_ws, T * ADAM_BX, l2_value);
     return xdfm_check_launch("adam_step");
