@@ -26,6 +26,8 @@
  * xdfm_cin_level_bwd_x_ex, xdfm_colsum, xdfm_head_fwd/bwd (K8), xdfm_adam_step (K7), xdfm_graph_node_census.
  * ABI 3: + xdfm_embed_scatter_bwd_marked and xdfm_adam_tensor.grad_marks (gradient buffer kept across steps),
  * xdfm_relu_bwd_colsum.
+ * ABI 4: K2 is a sorted, segmented, exact reduce (no atomics; same entry points), xdfm_adam_step_lr (learning rate
+ * from a device scalar), read-only options "last_fwd_kernel" / "last_bwx_kernel" / "last_bww_kernel".
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -37,7 +39,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 3
+#define XDFM_ABI_VERSION 4
 
 enum {
     XDFM_OK = 0,
@@ -60,6 +62,9 @@ int xdfm_device_count(void);                /* <0: HIP error code negated */
  *      error against an fp64 evaluation <= that of mode 0 (tests/test_gpu_parity.py); shapes without an
  *      f16x3 kernel (odd field counts in the forward, H <= 64 in dW, ...) run mode 0 kernels;
  *   0 "f32mfma": v_mfma_f32_32x32x2_f32 on the fp32 operands. */
+/* read-only probes (xdfm_get_option): "last_fwd_kernel", "last_bwx_kernel", "last_bww_kernel" = arithmetic of the kernel
+ * the last xdfm_cin_level_fwd / _bwd_x / _bwd_w call launched (0 f32mfma, 1 f16x3, 2 bf16; -1 before the first call):
+ * a shape without a kernel in the selected mode runs mode 0, and the tests assert which one ran. */
 int xdfm_set_option(const char* key, int value);
 int xdfm_get_option(const char* key);
 /* [host] node types of a captured hipGraph_t (the host side replays the train step from a HIP graph):
@@ -96,8 +101,13 @@ int xdfm_embed_gather_fwd(const float* X, long ldx, int B,
  * d_emb_fm [m][B*D] or NULL, d_dnn_in [B][m*D+nd] or NULL, d_lin [B] or NULL are the incoming
  * gradients.  The dense gradient tables live in ONE caller-initialised buffer d_flat (zeros, or the
  * L2 gradient written by xdfm_l2_reg_bwd): table j starts at d_flat + tab_off[j], its linear table
- * at d_flat + lin_off[j] (device long[m], element offsets; either may be NULL).  Row gradients are
- * accumulated with fp32 atomics; d_dense_w [nd] is accumulated too.
+ * at d_flat + lin_off[j] (device long[m], element offsets; either may be NULL); d_dense_w [nd] is added to as well.
+ * No atomics: per field the (id, example) keys of a chunk of <= 4096 examples are sorted in LDS, runs of equal ids
+ * are summed EXACTLY (addends rounded once to a fixed-point grid 2^-13 ulp below the run's largest magnitude, added
+ * as integers in doubles, rounded once to fp32) and added to d_flat by one lane per row.  The result is a function
+ * of the multiset of rows: bit-identical from run to run, under any permutation of the examples of a chunk and on
+ * every rank of a row-parallel run (the reference's CPU scatter, deepctr/inputs.py:168, is deterministic too; it adds
+ * in example order in fp32, i.e. within a few ulp of this).  Chunks (B > 4096) are launched in ascending order.
  */
 int xdfm_embed_scatter_bwd(const float* X, long ldx, int B,
                            const int* cols, const int* vocab, int m, int D,
@@ -280,6 +290,11 @@ typedef struct {
 size_t xdfm_adam_step_ws_elems(int T);
 int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double beta1, double beta2, double eps,
                    float* l2_ws, float* l2_value, void* stream);
+/* Same with the learning rate read from device memory when lr_dev != NULL (one double; `lr` is then ignored): a
+ * captured HIP graph of the step follows a learning-rate schedule (the host rewrites the scalar between replays)
+ * instead of being captured again for every value. */
+int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const double* lr_dev, double beta1, double beta2,
+                      double eps, float* l2_ws, float* l2_value, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,164 @@
+"""GPU tests (-m gpu) of the host logic around the captured train step and the drop-in behaviour of fit / predict:
+optimizer state reloads, learning-rate schedules, deferred IndexError for bad ids, pickling of a trained model, and
+the capture-after-collection incident of round 1 (tools/graph_crash_probe.py)."""
+import copy
+import gc
+import io
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+VOCAB, ND, D = [50, 31, 77, 12, 9, 40], 3, 8
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _model(dev, use_graph=True, cls=None, **kw):
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from xdfm_amd import graphstep
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(VOCAB)] + \
+        [DenseFeat("I%d" % (i + 1), 1) for i in range(ND)]
+    model = (cls or xDeepFM)(cols, cols, dnn_hidden_units=(32, 16), cin_layer_size=(16, 8), l2_reg_dnn=1e-5, device=dev, **kw)
+    model.compile("adam", "binary_crossentropy", metrics=[])
+    model.train()
+    step = graphstep.GraphedStep(model)
+    step.disabled = not use_graph
+    model.__dict__["_graphed_step"] = step
+    return model, step
+
+
+def _batch(s, rows=256):
+    from oracle import xdeepfm_oracle as orc
+    X, y = orc.synthetic_batch(rows, VOCAB, ND, seed=300 + s)
+    return T(X), T(y)
+
+
+def test_optimizer_state_reload_is_honoured_by_the_captured_step():
+    """the captured K7 launches bake the addresses of exp_avg / exp_avg_sq / step.  After
+    `optim.load_state_dict` (resume) those tensors are new ones; the graph key carries TableAdam.generation, so the
+    step is captured again instead of updating the old, freed buffers.  Graph run == eager twin throughout."""
+    dev = _dev()
+
+    def run(use_graph):
+        model, step = _model(dev, use_graph)
+        saved = None
+        for s in range(9):
+            if s == 2:
+                saved = copy.deepcopy(model.optim.state_dict())
+            if s == 5:
+                model.optim.load_state_dict(saved)            # moments and step counters go back to step 2
+            X, y = _batch(s)
+            model.train_on_batch(X.to(dev), y.to(dev))
+        return model, step
+
+    m_g, st_g = run(True)
+    m_e, st_e = run(False)
+    assert st_g.replays >= 3 and st_e.replays == 0 and not st_g.disabled
+    assert len([e for e in st_g.entries.values() if e.graph is not None]) == 2     # before and after the reload
+    for (k, a), (_, b) in zip(m_g.state_dict().items(), m_e.state_dict().items()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+    for pa, pb in zip(m_g.optim.param_groups[0]["params"], m_e.optim.param_groups[0]["params"]):
+        np.testing.assert_allclose(m_g.optim.state[pa]["exp_avg"].cpu().numpy(),
+                                   m_e.optim.state[pb]["exp_avg"].cpu().numpy(), rtol=1e-3, atol=1e-6)
+        assert float(m_g.optim.state[pa]["step"]) == float(m_e.optim.state[pb]["step"]) == 6.0
+
+
+def test_fit_and_predict_raise_index_error_for_ids_outside_the_vocabulary():
+    """The reference's nn.Embedding raises IndexError on an id >= vocabulary_size (basemodel.py:368-370).  K1 clamps and
+    raises a device flag; `fit` reads it with the epoch's losses, `predict` with its final copy."""
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    model, _ = _model(dev)
+    names = list(model.feature_index.keys())
+    X, y = orc.synthetic_batch(200, VOCAB, ND, seed=1)
+    ok = {n: X[:, i] for i, n in enumerate(names)}
+    model.fit(ok, y, batch_size=64, epochs=1, verbose=0)
+    model.predict(ok, 64)
+    Xb = X.copy()
+    Xb[137, 2] = VOCAB[2]                                       # one id == vocabulary_size (nunique instead of max + 1)
+    bad = {n: Xb[:, i] for i, n in enumerate(names)}
+    with pytest.raises(IndexError, match="vocabulary_size"):
+        model.predict(bad, 64)
+    model.predict(ok, 64)                                        # the flag was cleared
+    with pytest.raises(IndexError):
+        model.fit(bad, y, batch_size=64, epochs=1, verbose=0)
+    Xn = X.copy()
+    Xn[3, 0] = -1.0
+    with pytest.raises(IndexError):
+        model.predict({n: Xn[:, i] for i, n in enumerate(names)}, 64)
+
+
+def test_torch_save_of_the_whole_model_after_fit():
+    """ModelCheckpoint(save_weights_only=False) calls torch.save(model) (deepctr/callbacks.py:41-73): after a fit the
+    model holds a captured graph, ctypes descriptors and device-side plans -- they are dropped from the pickle and
+    rebuilt on first use."""
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    model, _ = _model(dev)
+    names = list(model.feature_index.keys())
+    X, y = orc.synthetic_batch(512, VOCAB, ND, seed=2)
+    data = {n: X[:, i] for i, n in enumerate(names)}
+    model.fit(data, y, batch_size=64, epochs=2, verbose=0)
+    assert model.__dict__["_graphed_step"].replays > 0
+    want = model.predict(data, 128)
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    twin = torch.load(buf, weights_only=False)                   # our own file
+    np.testing.assert_array_equal(twin.predict(data, 128), want)
+    twin.fit(data, y, batch_size=64, epochs=1, verbose=0)        # and it keeps training (plans / graph rebuilt)
+    model.fit(data, y, batch_size=64, epochs=1, verbose=0)
+    np.testing.assert_allclose(twin.predict(data, 128), model.predict(data, 128), rtol=1e-4, atol=1e-6)
+
+
+def test_tables_have_no_gradient_views_left_after_the_own_step():
+    """After the model's own step the tables' .grad must not stay views of the kept gradient buffer: a user loop
+    (backward -> step -> zero_grad) afterwards would accumulate into it unmarked."""
+    dev = _dev()
+    model, _ = _model(dev)
+    for s in range(4):
+        X, y = _batch(s)
+        model.train_on_batch(X.to(dev), y.to(dev))
+        assert all(p.grad is None for p in model.embedding_dict.parameters())
+        assert all(p.grad is None for p in model.linear_model.parameters())
+    arena, = model._plan.arenas()
+    torch.cuda.synchronize()
+    assert not arena.pending and float(arena.flat.abs().max()) == 0.0 and int(arena.marks.max()) == 0
+
+
+def test_capture_while_an_older_models_graphs_are_being_collected():
+    """Round-1 incident (gpurun_out/gputest2.log: segfault in capture_end): a graph owned by a dropped model was
+    destroyed by the cycle collector in the middle of a later capture.  Two models alive, the first one (with a
+    captured graph) dropped without an explicit collection, then the second one captures: the step object holds its
+    model weakly, unreachable graphs are destroyed before the capture begins and the collector is paused during it."""
+    dev = _dev()
+    m1, s1 = _model(dev)
+    m2, s2 = _model(dev)
+    for s in range(5):
+        X, y = _batch(s)
+        m1.train_on_batch(X.to(dev), y.to(dev))
+    assert s1.replays >= 2
+    for s in range(2):                                           # the two eager steps that precede m2's capture
+        X, y = _batch(s)
+        m2.train_on_batch(X.to(dev), y.to(dev))
+    cyc = [m1]                                                   # a reference cycle: only the collector can free m1
+    cyc.append(cyc)
+    del m1, s1, cyc
+    gc.enable()
+    out = None
+    for s in range(2, 8):
+        X, y = _batch(s)
+        junk = [[i] for i in range(2000)]                        # allocation pressure: generation-0 collections
+        out = m2.train_on_batch(X.to(dev), y.to(dev))
+        del junk
+    torch.cuda.synchronize()
+    assert s2.replays >= 4 and not s2.disabled
+    assert np.isfinite(float(out[2]))

@@ -3,7 +3,7 @@
 
 Tolerances (fp32 everywhere): forward values rtol 2e-5 / atol 2e-6 -- the MFMA contraction sums
 K = Hp*m products in a different order than ATen; gradients rtol 2e-4 with an absolute floor of
-2e-5 x max|expected| (dW sums B*D = thousands of terms with fp32 atomics in arbitrary order).
+2e-5 x max|expected| (dW sums B*D = thousands of terms in a different order than ATen).
 """
 import os
 
@@ -48,7 +48,7 @@ def cin_math(request):
 def test_native_library_is_loaded():
     from xdfm_amd import _lib
     lib = _lib.load()
-    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 4
     assert lib.xdfm_device_count() >= 1
     with open("/proc/self/maps") as f:
         assert "libxdfm_hip.so" in f.read()
@@ -387,6 +387,131 @@ def test_gather_scatter_vs_oracle():
         assert not plan.check_ids(dev)
 
 
+def _scatter_raw(X, vocab, nd, D, d_emb, d_dnn, d_lin, dev, with_marks=False):
+    """xdfm_embed_scatter_bwd_marked through the C ABI on host arrays -> (flat gradient buffer, offsets, marks)."""
+    import ctypes
+    from xdfm_amd import _lib
+    lib = _lib.load()
+    B, m = X.shape[0], len(vocab)
+    sizes = [v * D for v in vocab] + [v for v in vocab]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (n + 3) // 4 * 4
+    total = off
+    flat = torch.zeros(total + max(nd, 1) + 3, dtype=torch.float32, device=dev)
+    marks = torch.zeros(flat.numel() // 4 + 2, dtype=torch.uint8, device=dev) if with_marks else None
+    P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+    i32 = dict(dtype=torch.int32, device=dev)
+    cols, voc = torch.arange(m, **i32), torch.tensor(vocab, **i32)
+    dcols = torch.arange(m, m + max(nd, 1), **i32)
+    off_dev = torch.tensor(offs, dtype=torch.int64, device=dev)
+    Xd = T(X).to(dev)
+    de = None if d_emb is None else T(np.ascontiguousarray(d_emb.transpose(1, 0, 2).reshape(m, B * D))).to(dev)
+    dd = None if d_dnn is None else T(d_dnn).to(dev)
+    dl = None if d_lin is None else T(d_lin).to(dev)
+    dw = flat[total:total + nd] if nd else None
+    _lib.check(lib.xdfm_embed_scatter_bwd_marked(
+        P(Xd), Xd.stride(0), B, P(cols), P(voc), m, D, P(dcols) if nd else None, nd, P(de), P(dd), 0, P(dl), 0,
+        P(flat), P(off_dev[:m]), P(off_dev[m:]) if dl is not None else None, P(dw) if dl is not None else None,
+        P(marks), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "scatter")
+    torch.cuda.synchronize()
+    return flat.cpu().numpy(), offs, total, (marks.cpu().numpy() if with_marks else None)
+
+
+def _scatter_expected(X, vocab, nd, D, d_emb, d_dnn, d_lin):
+    """Per destination element: the fp32-rounded exact (float64) sum of its fp32 addends g = d_emb + d_dnn."""
+    B, m = X.shape[0], len(vocab)
+    g = np.zeros((B, m, D), dtype=np.float32)
+    if d_emb is not None:
+        g = g + d_emb
+    if d_dnn is not None:
+        g = (g + d_dnn[:, :m * D].reshape(B, m, D)).astype(np.float32)
+    tabs, lins = [], []
+    for j, v in enumerate(vocab):
+        ids = np.clip(X[:, j].astype(np.int64), 0, v - 1)
+        t = np.zeros((v, D), dtype=np.float64)
+        np.add.at(t, ids, g[:, j, :].astype(np.float64))
+        tabs.append(t)
+        l = np.zeros(v, dtype=np.float64)
+        if d_lin is not None:
+            np.add.at(l, ids, d_lin.astype(np.float64))
+        lins.append(l)
+    dw = None
+    if nd and d_lin is not None:
+        prod = (X[:, m:m + nd] * d_lin[:, None]).astype(np.float32)          # the kernel forms the products in fp32
+        dw = prod.astype(np.float64).sum(0)
+    return tabs, lins, dw
+
+
+@pytest.mark.parametrize("B,vocab,nd,D,srcs", [
+    (4096, [1000] * 26, 13, 16, "edl"),          # BASELINE config 2 shape: Zipf ids, hot rows of hundreds of examples
+    (4096, [3, 1, 100000, 7] * 2, 2, 16, "edl"),    # a whole chunk on ONE row (vocab 1) and on three rows
+    (5000, [50] * 5, 3, 32, "edl"),              # two chunks (4096 + 904) and two 16-column slices per field
+    (777, [11, 300, 5], 0, 10, "ed"),            # D not a multiple of 4 (scalar lanes), no dense part, no linear part
+    (64, [9] * 4, 1, 8, "d"),                    # only the DNN-side gradient
+    (1, [4, 4], 0, 3, "e"),
+])
+def test_scatter_is_exact_deterministic_and_order_independent(B, vocab, nd, D, srcs):
+    """K2 (`embed_scatter_sorted_kernel`): sorted, segmented, atomics-free reduce of the row gradients.  Checked here:
+    (1) every element equals the fp32 rounding of the EXACT sum of its addends (float64 reference; the reference's
+        CPU `embedding_dense_backward`, deepctr/inputs.py:168, sums the same addends in fp32 in example order, i.e.
+        within a few ulp of this);
+    (2) two runs give bit-identical buffers;
+    (3) a permutation of the examples gives bit-identical buffers (SURVEY 8e: identical scatter on every rank);
+    (4) the chunk marks cover exactly the touched 16-byte chunks."""
+    dev = _dev()
+    m = len(vocab)
+    rng = np.random.default_rng(B + D)
+    X = np.zeros((B, m + nd), dtype=np.float32)
+    for j, v in enumerate(vocab):
+        X[:, j] = np.floor(v * rng.random(B) ** 3)
+    X[:, m:] = rng.random((B, nd))
+    mag = 10.0 ** rng.integers(-6, 2, size=(B, 1, 1))                       # rows of very different magnitudes
+    d_emb = (rng.standard_normal((B, m, D)) * mag).astype(np.float32) if "e" in srcs else None
+    d_dnn = (rng.standard_normal((B, m * D + nd)) * mag[:, 0]).astype(np.float32) if "d" in srcs else None
+    d_lin = (rng.standard_normal(B) * mag[:, 0, 0]).astype(np.float32) if "l" in srcs else None
+    flat, offs, total, marks = _scatter_raw(X, vocab, nd, D, d_emb, d_dnn, d_lin, dev, with_marks=True)
+    tabs, lins, dw = _scatter_expected(X, vocab, nd, D, d_emb, d_dnn, d_lin)
+    multi = B > 4096         # more than one chunk: the chunks' exact sums are added in fp32, in chunk order
+    for j, v in enumerate(vocab):
+        got = flat[offs[j]:offs[j] + v * D].reshape(v, D)
+        if multi:
+            np.testing.assert_allclose(got, tabs[j], rtol=3e-7, atol=3e-7 * np.abs(tabs[j]).max())
+        else:
+            np.testing.assert_array_equal(got, tabs[j].astype(np.float32), err_msg="table %d" % j)
+        gl = flat[offs[m + j]:offs[m + j] + v]
+        if multi:
+            np.testing.assert_allclose(gl, lins[j], rtol=3e-7, atol=3e-7 * np.abs(lins[j]).max())
+        else:
+            np.testing.assert_array_equal(gl, lins[j].astype(np.float32), err_msg="linear table %d" % j)
+    if dw is not None:
+        if multi:
+            np.testing.assert_allclose(flat[total:total + nd], dw, rtol=3e-7, atol=3e-7 * np.abs(dw).max())
+        else:
+            np.testing.assert_array_equal(flat[total:total + nd], dw.astype(np.float32))
+    # (4) marks: a chunk is marked iff the scatter wrote into it
+    touched = np.zeros(flat.size // 4 + 2, dtype=bool)
+    for j, v in enumerate(vocab):
+        ids = np.unique(np.clip(X[:, j].astype(np.int64), 0, v - 1))
+        e = (offs[j] + ids[:, None] * D + np.arange(D)[None, :]).reshape(-1)
+        touched[e >> 2] = True
+        if d_lin is not None:
+            touched[(offs[m + j] + ids) >> 2] = True
+    if dw is not None:
+        touched[(total + np.arange(nd)) >> 2] = True
+    np.testing.assert_array_equal(marks.astype(bool), touched)
+    # (2) run to run
+    flat2, _, _, _ = _scatter_raw(X, vocab, nd, D, d_emb, d_dnn, d_lin, dev)
+    np.testing.assert_array_equal(flat2.view(np.uint32), flat.view(np.uint32))
+    # (3) permuted examples (within one chunk the result is a function of the multiset of rows)
+    if not multi:
+        p = rng.permutation(B)
+        pick = lambda a: None if a is None else np.ascontiguousarray(a[p])
+        flat3, _, _, _ = _scatter_raw(np.ascontiguousarray(X[p]), vocab, nd, D, pick(d_emb), pick(d_dnn), pick(d_lin), dev)
+        np.testing.assert_array_equal(flat3.view(np.uint32), flat.view(np.uint32))
+
+
 def test_gather_flags_out_of_range_ids():
     from xdfm_amd import ops
     dev = _dev()
@@ -562,9 +687,9 @@ def test_full_size_logloss_auc_vs_cpu_path():
 
 def test_graph_replay_of_train_step_matches_eager_launches():
     """xdfm_amd/graphstep.py: from the third step on the train step is replayed from a captured HIP graph.
-    Same seed, same batches: the replayed run must follow the eager run (difference = fp32 atomics order of
-    the embedding scatter only), the captured graph must hold no memset node, and a change of what is baked
-    into the graph (here the learning rate) must re-capture instead of replaying stale launches."""
+    Same seed, same batches: the replayed run must follow the eager run, the captured graph must hold no memset
+    node, and a change of the learning rate must be FOLLOWED by the same graph (K7 reads the rate from a device
+    scalar, TableAdam.sync_lr) instead of forcing a new capture per value (a schedule would thrash the cache)."""
     from deepctr.inputs import DenseFeat, SparseFeat
     from deepctr.models import xDeepFM
     from oracle import xdeepfm_oracle as orc
@@ -595,7 +720,7 @@ def test_graph_replay_of_train_step_matches_eager_launches():
     assert step_e.replays == 0 and step_g.replays >= 6, (step_g.replays, step_g.disabled)
     assert not step_g.disabled
     graphs = [e for e in step_g.entries.values() if e.graph is not None]
-    assert len(graphs) == 2                                   # lr 1e-3 and lr 3e-3, batch 256
+    assert len(graphs) == 1                                   # batch 256: ONE graph serves lr 1e-3 and lr 3e-3
     for e in graphs:
         n, n_memset, n_other = graphstep.census(e.graph)
         assert n > 20 and n_memset == 0 and n_other == 0

@@ -38,7 +38,11 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 struct AdamBatch { xdfm_adam_tensor t[ADAM_CHUNK]; };
 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
-    const AdamBatch batch, int t0, double lr, double beta1, double beta2, double eps, float* __restrict__ l2_part) {
+    const AdamBatch batch, int t0, double lr_arg, const double* __restrict__ lr_dev, double beta1, double beta2, double eps,
+    float* __restrict__ l2_part) {
+    // the learning rate as a kernel argument, or read from device memory (a captured HIP graph then follows a
+    // learning-rate schedule without being captured again)
+    const double lr = lr_dev ? *lr_dev : lr_arg;
     // gridDim.x blocks per tensor (ADAM_BX by default; fewer = a small footprint that can share the chip with an
     // MFMA-bound kernel on another stream); the L2 partials keep their ADAM_BX slots per tensor
     const xdfm_adam_tensor& d = batch.t[blockIdx.y];
@@ -169,6 +173,11 @@ size_t xdfm_adam_step_ws_elems(int T) { return T > 0 ? (size_t)T * ADAM_BX : 0; 
 
 int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double beta1, double beta2, double eps,
                    float* l2_ws, float* l2_value, void* stream) {
+    return xdfm_adam_step_lr(tensors, T, lr, nullptr, beta1, beta2, eps, l2_ws, l2_value, stream);
+}
+
+int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const double* lr_dev, double beta1, double beta2,
+                      double eps, float* l2_ws, float* l2_value, void* stream) {
     XDFM_REQUIRE(tensors, "adam_step: null pointer");
     XDFM_REQUIRE(T > 0 && T <= 65535, "adam_step: bad tensor count %d", T);
     XDFM_REQUIRE(lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "adam_step: bad hyper-parameters");
@@ -196,7 +205,7 @@ int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double bet
         for (int k = cnt; k < ADAM_CHUNK; ++k) batch.t[k] = batch.t[0];
         int bx = xdfm_opt(OPT_ADAM_BX);
         if (bx <= 0 || bx > ADAM_BX) bx = ADAM_BX;
-        hipLaunchKernelGGL(adam_step_kernel, dim3(bx, cnt), dim3(ADAM_THREADS), 0, st, batch, slot0, lr, beta1, beta2, eps,
+        hipLaunchKernelGGL(adam_step_kernel, dim3(bx, cnt), dim3(ADAM_THREADS), 0, st, batch, slot0, lr, lr_dev, beta1, beta2, eps,
                            l2_value ? l2_ws : nullptr);
         slot0 += cnt;
     }

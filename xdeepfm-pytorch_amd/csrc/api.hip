@@ -16,8 +16,11 @@ static int g_opts[OPT_COUNT] = {
     /* OPT_X3_WAVES */ 0,
     /* OPT_BWW_PHASE */ 0,
     /* OPT_ADAM_BX */ 0,
+    /* OPT_LAST_FWD */ -1,
+    /* OPT_LAST_BWX */ -1,
+    /* OPT_LAST_BWW */ -1,
 };
-static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math", "x3_fwd_mt", "x3_bwx_rows", "x3_waves", "bww_phase", "adam_bx"};
+static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math", "x3_fwd_mt", "x3_bwx_rows", "x3_waves", "bww_phase", "adam_bx", "last_fwd_kernel", "last_bwx_kernel", "last_bww_kernel"};
 
 int xdfm_fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -28,6 +31,7 @@ int xdfm_fail(int code, const char* fmt, ...) {
 }
 
 int xdfm_opt(int idx) { return g_opts[idx]; }
+void xdfm_opt_note(int idx, int value) { g_opts[idx] = value; }
 
 extern "C" {
 

@@ -778,7 +778,8 @@ int xdfm_cin_level_bwd_x_ex(const float* dOut, const float* xp, const float* x0,
     XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_x: bad shape H=%d (<=256) Hp=%d m=%d",
                  H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_bwx_usable(H, Hp, m)) return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
+    if (x3_bwx_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_BWX, 1); return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st); }
+    xdfm_opt_note(OPT_LAST_BWX, 0);
     switch (bwx_hs4(H)) {
         case 1: return launch_bwd_x<1>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
         case 2: return launch_bwd_x<2>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
@@ -805,7 +806,8 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, in
     XDFM_REQUIRE(dOut && xp && x0 && ws && dW, "cin_level_bwd_w: null pointer");
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_w: bad shape H=%d Hp=%d m=%d", H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_bww_usable(dOut, xp, x0, H, N)) return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
+    if (x3_bww_usable(dOut, xp, x0, H, N)) { xdfm_opt_note(OPT_LAST_BWW, 1); return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, st); }
+    xdfm_opt_note(OPT_LAST_BWW, 0);
     const int phase = xdfm_opt(OPT_BWW_PHASE);            // fp32 kernels: the whole call counts as phase 2
     if (phase == 1 || phase == 3) return XDFM_OK;
     switch (bww_mt(H)) {

@@ -13,6 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // error plumbing (api.hip)
 int xdfm_fail(int code, const char* fmt, ...);
 int xdfm_opt(int idx);
+void xdfm_opt_note(int idx, int value);    // library-internal: record a probe value
 enum {
     OPT_FWD_NF = 0,      // column fragments (32 cols each) per wave in the forward kernel: 1 or 2
     OPT_BWW_NSPLIT,      // 0 = auto; n-range splits of the dW kernel
@@ -25,6 +26,9 @@ enum {
     OPT_X3_WAVES,        // 0 = auto (8 waves per workgroup share a weight ring where the piece count allows); 4 = force 4
     OPT_BWW_PHASE,       // 0 = whole dW call; 1 / 2 / 3 = only the pre-passes / the MFMA kernel / the slab sum (f16x3; timing)
     OPT_ADAM_BX,         // 0 = default (128); blocks per tensor of the Adam kernel
+    OPT_LAST_FWD,        // read-only probes: arithmetic of the kernel the last xdfm_cin_level_fwd / _bwd_x / _bwd_w call
+    OPT_LAST_BWX,        //   launched: 0 = v_mfma_f32_32x32x2_f32, 1 = f16x3, 2 = bf16 (tests assert which kernel ran)
+    OPT_LAST_BWW,
     OPT_COUNT
 };
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "xdfm_head_bwd": (c_int, [P, P, P, P, P, c_int, P, P, c_int, c_int, P, P, P, P, P, P]),
     "xdfm_adam_step_ws_elems": (c_size_t, [c_int]),
     "xdfm_adam_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, P, P, P]),
+    "xdfm_adam_step_lr": (c_int, [P, c_int, c_double, P, c_double, c_double, c_double, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
     "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
     "xdfm_relu_bwd_colsum": (c_int, [P, P, c_long, c_int, c_long, c_long, P, P, P, P]),
@@ -68,7 +69,7 @@ class AdamTensor(ctypes.Structure):
                 ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float), ("grad_marks", c_void_p)]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _lib = None
 
 

@@ -48,17 +48,29 @@ class RowParallel(object):
 
     # ---------------------------------------------------------------- sharding
     def shard(self, t):
-        """This rank's rows of a global-batch tensor (every rank sees the same global batch)."""
+        """This rank's rows of a global-batch tensor (every rank sees the same global batch).  A global batch with
+        fewer rows than ranks (the tail of an epoch) leaves some ranks without rows: such a rank takes row 0 as a
+        stand-in, so that it still runs the step and joins every collective, and differentiates it with weight 0
+        (`row_weight`): its data gradients are exact zeros and its rows are not part of the gathered metrics."""
         n = t.shape[0]
-        if n < self.world:
-            raise ValueError("global batch of %d rows cannot be split over %d ranks" % (n, self.world))
+        if n < 1:
+            raise ValueError("empty global batch")
         p = split_points(n, self.world)
         self._n_global = n
-        return t[p[self.rank]:p[self.rank + 1]]
+        lo, hi = p[self.rank], p[self.rank + 1]
+        return t[lo:hi] if hi > lo else t[0:1]
 
     def local_sizes(self):
+        """Rows per rank that belong to the global batch (0 for a rank that only holds a stand-in row)."""
         p = split_points(self._n_global, self.world)
         return [p[r + 1] - p[r] for r in range(self.world)]
+
+    def step_sizes(self):
+        """Rows per rank that take part in the step (a stand-in row counts)."""
+        return [max(s, 1) for s in self.local_sizes()]
+
+    def row_weight(self):
+        return 1.0 if self.local_sizes()[self.rank] > 0 else 0.0
 
     # ---------------------------------------------------------------- collectives
     def _via_host(self, t):
@@ -97,7 +109,10 @@ class RowParallel(object):
         return bool(self.all_reduce_sum(v).item() > 0)
 
     def gather_rows(self, v):
-        return torch.cat(self.all_gather_padded(v, self.local_sizes()), dim=0)
+        sizes = self.local_sizes()
+        if sizes[self.rank] == 0:
+            v = v[:0]                          # a stand-in row is not part of the global batch
+        return torch.cat(self.all_gather_padded(v, sizes), dim=0)
 
     # ---------------------------------------------------------------- gradient exchange
     def mark_replicated(self, params):
@@ -140,7 +155,7 @@ class RowParallel(object):
         batch) pad with zero rows, which scatter exact zeros.  The gathered buffer is handed to the scatter as
         strided views, so every rank runs ONE scatter launch over all ranks' rows in rank order; no transposes, no
         per-rank launches.  Returns [(X, None, row_grads, d_lin)] for EmbedGather.scatter."""
-        sizes = self.local_sizes()
+        sizes = self.step_sizes()
         B = X.shape[0]
         if B != sizes[self.rank]:
             raise RuntimeError("exchange_rows: local batch %d does not match the sharded size %d" % (B, sizes[self.rank]))

@@ -67,13 +67,19 @@ class GraphedStep(object):
     def _signature(self):
         m = self.model
         opt = m.optim
+        # the learning rate is NOT baked in when the optimizer hands it to K7 through a device scalar (TableAdam.sync_lr)
+        lr_free = hasattr(opt, "sync_lr")
         hyper = tuple(tuple((k, (v if isinstance(v, (int, float, bool, str, tuple, type(None))) else id(v)))
-                            for k, v in sorted(pg.items()) if k != "params") for pg in opt.param_groups)
+                            for k, v in sorted(pg.items()) if k != "params" and not (lr_free and k == "lr" and isinstance(v, float)))
+                      for pg in opt.param_groups)
         ptrs, req = 0, 0
         for p in m.parameters():
             ptrs = (ptrs * 1000003 + p.data_ptr()) & 0xFFFFFFFFFFFFFFF
             req = (req << 1 | int(p.requires_grad)) & 0xFFFFFFFFFFFFFFF
-        return (id(opt), hyper, ptrs, req, id(m.loss_func), m.training, id(m.aux_loss), _lib.get_option("cin_math"))
+        # the optimizer's state tensors are baked into the captured K7 launches by address: `generation` changes
+        # whenever they may have been replaced (load_state_dict, unpickling, add_param_group)
+        return (id(opt), getattr(opt, "generation", 0), hyper, ptrs, req, id(m.loss_func), m.training, id(m.aux_loss),
+                _lib.get_option("cin_math"))
 
     def eligible(self, x, y):
         m = self.model
@@ -94,6 +100,8 @@ class GraphedStep(object):
         m = self.model
         if not self.eligible(x, y):
             return m._train_step_eager(x, y)
+        if hasattr(m.optim, "sync_lr"):
+            m.optim.sync_lr()              # outside any capture: the device scalar K7 reads follows param_groups["lr"]
         dp = xdist.current()
         key = (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype, x.device.index, self._signature(),
                None if dp is None else dp.world)

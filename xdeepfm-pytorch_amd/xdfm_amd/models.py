@@ -91,6 +91,11 @@ class Linear(nn.Module):
     def tables(self):
         return [self.embedding_dict[fc.embedding_name].weight for fc in self.sparse_feature_columns]
 
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_plan"] = None
+        return state
+
     def forward(self, X, sparse_feat_refine_weight=None):
         if sparse_feat_refine_weight is not None:
             raise NotImplementedError("refine weights belong to IFM/DIFM, not to the xDeepFM path")
@@ -139,6 +144,56 @@ class BaseModel(nn.Module):
         self.history = History()
         self.stop_training = False
         self._plan = None
+
+    # ------------------------------------------------------------------ pickling (ModelCheckpoint with
+    # save_weights_only=False calls torch.save(model), deepctr/callbacks.py:41-73)
+    _UNPICKLED = ("_graphed_step", "_plan", "_l2_cache", "_unit_grad_cache", "_sparse_cols", "_fused_linear", "_own_step",
+                  "_row_weight")
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._UNPICKLED:           # captured graphs, ctypes descriptors, device-side plans: rebuilt on first use
+            state.pop(k, None)
+        state["_plan"] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__.setdefault("_plan", None)
+        lm = self.__dict__.get("_modules", {}).get("linear_model")
+        if lm is not None:
+            lm._plan = None
+
+    def _plans(self):
+        plans = [self._plan, getattr(self.linear_model, "_plan", None)]
+        return [p for p in plans if p is not None]
+
+    def _raise_on_bad_ids(self):
+        """The reference's nn.Embedding raises IndexError (CPU) or device-asserts on an id outside [0, vocabulary_size)
+        (basemodel.py:368-370).  K1 clamps such an id and raises a device flag instead of stopping the stream; the flag
+        is read where the host synchronises anyway -- the per-epoch loss read-back of `fit`, the final copy of
+        `predict` / `evaluate` -- so the error is deferred to the end of the epoch / call, never lost."""
+        dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
+        if dev.type != "cuda":
+            return
+        for plan in self._plans():
+            if plan.check_ids(dev):
+                bounds = ", ".join("%d" % v for v in plan.vocab[:8]) + (" ..." if len(plan.vocab) > 8 else "")
+                raise IndexError("index out of range in self: a sparse feature id lies outside [0, vocabulary_size) "
+                                 "(vocabulary sizes: %s) -- check SparseFeat(vocabulary_size=max_id + 1)" % bounds)
+
+    def _drop_table_grads(self):
+        """After the model's own step the tables' `.grad` are views of the kept gradient buffer (all zeros again once K7
+        has consumed them).  They are released so that code which drives autograd itself afterwards gets fresh dense
+        gradients instead of accumulating into that buffer behind the optimizer's back."""
+        tables = self._gather_tables()
+        if tables is None or self._plan is None or not self._plan.arenas():
+            return
+        for t in tables:
+            t.grad = None
+        w = getattr(self.linear_model, "weight", None)
+        if w is not None:
+            w.grad = None
 
     # ------------------------------------------------------------------ fused input stage
     def _gather_plan(self):
@@ -354,7 +409,11 @@ class BaseModel(nn.Module):
                 self._plan.arena_on = False
 
     def _unit_grad(self, loss):
-        """Root gradient of a backward pass, cached: autograd would otherwise fill a fresh ones tensor every step."""
+        """Root gradient of a backward pass, cached: autograd would otherwise fill a fresh ones tensor every step.
+        A rank that holds only a stand-in row (a global batch with fewer rows than ranks, dist.RowParallel.shard)
+        differentiates with a zero root: all its data gradients are exact zeros."""
+        if self.__dict__.get("_row_weight", 1.0) == 0.0:
+            return torch.zeros_like(loss)
         key = (tuple(loss.shape), loss.device, loss.dtype)
         hit = self.__dict__.get("_unit_grad_cache")
         if hit is None or hit[0] != key:
@@ -380,7 +439,9 @@ class BaseModel(nn.Module):
 
     def _split_step_second(self, y_pred, loss, stash, fuse):
         with self._own_step_scope():
-            return self._split_step_second_body(y_pred, loss, stash, fuse)
+            out = self._split_step_second_body(y_pred, loss, stash, fuse)
+        self._drop_table_grads()
+        return out
 
     def _split_step_second_body(self, y_pred, loss, stash, fuse):
         dp = xdist.current()
@@ -403,7 +464,9 @@ class BaseModel(nn.Module):
 
     def _train_step_eager(self, x, y):
         with self._own_step_scope():
-            return self._train_step_eager_body(x, y)
+            out = self._train_step_eager_body(x, y)
+        self._drop_table_grads()
+        return out
 
     def _train_step_eager_body(self, x, y):
         dp = xdist.current()
@@ -432,7 +495,7 @@ class BaseModel(nn.Module):
             # Dense weights: all-reduce the data gradients, then add the L2 gradient locally.
             reg_t = self.get_regularization_loss(_defer_tables=True, _part="tables")
             reg_d = self.get_regularization_loss(_part="rest")
-            (loss + reg_t).backward()
+            (loss * self.__dict__.get("_row_weight", 1.0) + reg_t).backward()
             dp.reduce_dense_grads(self)
             (reg_d + self.aux_loss).backward()
             total_loss = loss.detach() + reg_t.detach() + reg_d.detach() + self.aux_loss
@@ -600,9 +663,14 @@ class BaseModel(nn.Module):
                     yb = self._rows(Y_all, order, start, start + global_bs)
                     if dp is not None:
                         xb, yb = dp.shard(xb), dp.shard(yb)
+                        self.__dict__["_row_weight"] = dp.row_weight()
                     xd = xb.to(self.device)
                     yd = yb.to(self.device)
                     y_pred, loss, total_loss = self.train_on_batch(xd, yd)
+                    if dp is not None and dp.row_weight() == 0.0:
+                        # stand-in row of a rank without rows in this (tail) batch: contributes nothing
+                        total_loss = total_loss - loss
+                        loss = loss * 0.0
                     # The reference reads the loss back every step (`total_loss.item()`, basemodel.py:262): a host
                     # sync per step that leaves the GPU idle while the next step is being enqueued.  The values are
                     # parked on the device instead and read once per epoch, summed in the same order in double.
@@ -633,6 +701,7 @@ class BaseModel(nn.Module):
                 raise
             if bar is not None:
                 bar.close()
+            self.__dict__["_row_weight"] = 1.0
             if step_no:
                 data_l, total_l = loss_log[:step_no, 0], loss_log[:step_no, 1]
                 if dp is not None:
@@ -643,6 +712,7 @@ class BaseModel(nn.Module):
                     vals = total_l.tolist()
                 for v in vals:
                     total_loss_epoch += v
+            self._raise_on_bad_ids()          # deferred IndexError of the epoch's gathers (host is in sync here anyway)
             epoch_logs["loss"] = total_loss_epoch / sample_num
             for name, k in logged.items():
                 vals = metric_log[:step_no, k].tolist()
@@ -689,7 +759,9 @@ class BaseModel(nn.Module):
                 chunks.append(self(X_all[start:start + batch_size].to(self.device)))
         if not chunks:
             return np.zeros((0, 1), dtype="float64")
-        return torch.cat(chunks).cpu().data.numpy().astype("float64")     # one device-to-host copy
+        out = torch.cat(chunks).cpu().data.numpy().astype("float64")      # one device-to-host copy
+        self._raise_on_bad_ids()
+        return out
 
 
 # ------------------------------------------------------------------------------------------------- #

@@ -27,6 +27,63 @@ class TableAdam(torch.optim.Adam):
         self._desc = {}             # group index -> (key, ctypes array of xdfm_adam_tensor)
         self.l2_value = None        # [1] device tensor: value of the armed L2 term at the last step
         self.grad_sources = []      # objects with .arenas() -> [ops.GradArena]: gradients K7 may read by their marks
+        self._lr_dev = {}           # group index -> (host value, [1] float64 device tensor K7 reads the rate from)
+        self.generation = 0         # bumped whenever state tensors may have been replaced (part of the graph key)
+
+    # K7 takes the learning rate from device memory, so a captured train step follows `param_groups[i]["lr"]` edits
+    # (schedules, the reference's lr override xdftrain.py:283-284) without a new capture.  The scalar is rewritten
+    # OUTSIDE any capture: GraphedStep calls sync_lr() before every replay, step() calls it for eager launches.
+    def sync_lr(self):
+        for gi, group in enumerate(self.param_groups):
+            lr = group["lr"]
+            if not isinstance(lr, float) or not group["params"]:
+                continue
+            hit = self._lr_dev.get(gi)
+            dev = group["params"][0].device
+            if hit is None or hit[1].device != dev:
+                if dev.type != "cuda" or torch.cuda.is_current_stream_capturing():
+                    continue
+                hit = self._lr_dev[gi] = [None, torch.empty(1, dtype=torch.float64, device=dev)]
+            if hit[0] != lr:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("xdfm TableAdam: learning rate changed inside a HIP-graph capture")
+                hit[1].fill_(lr)
+                hit[0] = lr
+
+    def load_state_dict(self, state_dict):
+        out = super().load_state_dict(state_dict)
+        self._invalidate()
+        return out
+
+    def add_param_group(self, param_group):
+        out = super().add_param_group(param_group)
+        if hasattr(self, "_desc"):
+            self._invalidate()
+        return out
+
+    def _invalidate(self):
+        """State tensors (exp_avg, exp_avg_sq, step) may have been replaced: forget the cached descriptors, and make
+        every captured graph that baked their addresses stale (graphstep._signature hashes `generation`)."""
+        self._desc = {}
+        self._lr_dev = {}
+        self.generation += 1
+
+    def __getstate__(self):
+        state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
+        state = dict(state)
+        for k in ("_desc", "_lr_dev", "_armed", "l2_value"):      # ctypes descriptors / device scalars: rebuilt on use
+            state[k] = {} if k in ("_desc", "_lr_dev") else None
+        state["grad_sources"] = []
+        return state
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__.setdefault("_desc", {})
+        self.__dict__.setdefault("_lr_dev", {})
+        self.__dict__.setdefault("_armed", None)
+        self.__dict__.setdefault("l2_value", None)
+        self.__dict__.setdefault("grad_sources", [])
+        self.generation = self.__dict__.get("generation", 0) + 1
 
     def owns(self, tensors):
         mine = {id(p) for g in self.param_groups for p in g["params"]}
@@ -65,6 +122,7 @@ class TableAdam(torch.optim.Adam):
                 self._l2_by_hand(armed)
             return super().step(closure)
         self._cuda_graph_capture_health_check()
+        self.sync_lr()
         lib = _lib.load()
         for gi, group in enumerate(self.param_groups):
             params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps = [], [], [], [], [], []
@@ -106,9 +164,11 @@ class TableAdam(torch.optim.Adam):
                 ws = torch.empty(lib.xdfm_adam_step_ws_elems(T), dtype=torch.float32, device=dev)
                 val = torch.empty(1, dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(lib.xdfm_adam_step(ctypes.cast(arr, ctypes.c_void_p), T, float(group["lr"]), float(beta1),
-                                          float(beta2), float(group["eps"]), ws.data_ptr() if ws is not None else None,
-                                          val.data_ptr() if val is not None else None, stream), "adam_step")
+            lr_dev = self._lr_dev.get(gi)
+            _lib.check(lib.xdfm_adam_step_lr(ctypes.cast(arr, ctypes.c_void_p), T, float(group["lr"]),
+                                             lr_dev[1].data_ptr() if lr_dev is not None else None, float(beta1),
+                                             float(beta2), float(group["eps"]), ws.data_ptr() if ws is not None else None,
+                                             val.data_ptr() if val is not None else None, stream), "adam_step")
             if val is not None:
                 self.l2_value = val if self.l2_value is None else self.l2_value + val
         return None
