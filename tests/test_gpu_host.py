@@ -114,8 +114,8 @@ def test_torch_save_of_the_whole_model_after_fit():
     buf.seek(0)
     twin = torch.load(buf, weights_only=False)                   # our own file
     np.testing.assert_array_equal(twin.predict(data, 128), want)
-    twin.fit(data, y, batch_size=64, epochs=1, verbose=0)        # and it keeps training (plans / graph rebuilt)
-    model.fit(data, y, batch_size=64, epochs=1, verbose=0)
+    twin.fit(data, y, batch_size=64, epochs=1, verbose=0, shuffle=False)     # and it keeps training (plans / graph rebuilt)
+    model.fit(data, y, batch_size=64, epochs=1, verbose=0, shuffle=False)
     np.testing.assert_allclose(twin.predict(data, 128), model.predict(data, 128), rtol=1e-4, atol=1e-6)
 
 

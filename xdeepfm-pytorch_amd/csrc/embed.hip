@@ -160,31 +160,34 @@ __global__ __launch_bounds__(EMB_THREADS) void embed_gather_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2 backward: dense table gradients from the row gradients, WITHOUT atomics -- a sorted, segmented, exact reduce.
+// K2 backward: dense table gradients from the row gradients, WITHOUT atomics on the gradients -- a grouped,
+// segmented, exact reduce.
 //
 // The reference's embedding_dense_backward (deepctr/inputs.py:168, sparse=False) adds the rows of one id in example
 // order on the CPU: deterministic.  Arrival-order fp32 atomics are not (replicated tables of a row-parallel run
 // drift apart in the last bits), and a hot id serialises thousands of atomics on one row.  Here one workgroup owns
-// one (field, 16-column slice) of a chunk of <= SC_ROWS examples:
-//   S   sort the chunk's (id, example) keys of the field in LDS (bitonic network on 64-bit composite keys);
-//   1   walk the sorted list in windows of 8 positions (4 lanes per window, one float4 of the row each, all 8 row
-//       loads of a window in flight): runs of equal ids that lie inside a window are summed and written at once;
+// one (field, 4-column slice) -- or one field's linear table -- of a chunk of <= SC_ROWS examples:
+//   G   group the chunk's examples by id in LDS: open-addressing hash slots (atomicCAS on integers), a count per
+//       slot, an exclusive scan, a placement pass -- O(n); equal ids end up adjacent (a "run"), in no particular order;
+//   1   one thread per window of 8 list positions: its 8 row pieces (float4) are loaded at once and stay in
+//       registers; runs that lie inside the window are summed, and all their read-modify-writes of d_flat are
+//       issued together;
 //   2-4 runs that cross windows: their owner (the window where the run starts) collects the pieces through LDS.
 // Every sum is EXACT: the addends of a run are rounded once to a fixed-point grid 2^-s derived from the run's
 // largest magnitude (s = 37 - exponent: the grid is 2^-13 of an fp32 ulp of that magnitude or finer) and added as
 // integers held in doubles (< 2^52, so every addition is exact), then rounded once to fp32.  The result is a pure
-// function of the MULTISET of rows of an id: independent of the order of the examples, of the window cuts and of
-// the hardware -- bit-identical on every rank and under any permutation of the batch (tests/test_gpu_parity.py).
-// One row is written by exactly one lane (read-modify-write of d_flat, which holds zeros or the L2 gradient).
+// function of the MULTISET of rows of an id -- which is why the order inside the grouped list (it depends on
+// which lane wins a hash slot) does not matter: bit-identical from run to run, on every rank and under any
+// permutation of the batch (tests/test_gpu_parity.py).  One row is written by exactly one lane (read-modify-write
+// of d_flat, which holds zeros or the L2 gradient).
 #define SC_THREADS 512
-#define SC_ROWS 4096          // examples per chunk (LDS: 8 B of key per example + 25.5 B of slots per example)
-#define SC_W 8                // sorted positions per window
-#define SC_SW 16              // embedding columns per workgroup slice (4 lanes x float4)
-#define SC_NC 5               // components per lane: 4 columns + the linear-table gradient (lane 0 of slice 0)
-#define SC_NOID 0xffffffffu
-// keys live at padded positions (one spare slot after every 8): a thread's 8 consecutive keys and a wave's
-// consecutive keys are both free of LDS bank conflicts
-#define SC_K(i) ((i) + ((i) >> 3))
+#define SC_ROWS 4096          // examples per chunk = SC_THREADS windows of SC_W
+#define SC_W 8                // list positions per window
+#define SC_SW 4               // embedding columns per workgroup slice (one float4 per row and lane)
+#define SC_NC 4               // components per lane (a linear-table workgroup uses component 0 only)
+#define SC_EMPTY 0xffffffffu
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte load from a 4-byte aligned address
 
 __device__ __forceinline__ int sc_scale_exp(float amax) {
     // s with amax * 2^s in [2^37, 2^38): the sum of <= 2^13 such addends stays below 2^51
@@ -194,123 +197,38 @@ __device__ __forceinline__ int sc_scale_exp(float amax) {
 __device__ __forceinline__ double sc_pow2(int s) { return __longlong_as_double((long long)(1023 + s) << 52); }
 __device__ __forceinline__ double sc_fix(float v, double sc) { return __builtin_rint((double)v * sc); }
 
-__host__ __device__ inline size_t sc_keys_bytes(int npad) { return (size_t)(SC_K(npad + 8) + 1) * 8; }
-
-struct ScWin {                 // one window of the sorted list, as every lane of its group sees it
-    unsigned id[SC_W];
-    int b[SC_W];
-    int count;                 // live positions (the last window of a chunk may be short)
-    bool contL, contR;         // first run continues from the previous window / last run continues into the next
-};
-
-__device__ __forceinline__ void sc_window(const unsigned long long* keys, int w, int nb, ScWin& W) {
-    const int base = w * SC_W;
-    W.count = nb - base < SC_W ? nb - base : SC_W;
-#pragma unroll
-    for (int q = 0; q < SC_W; ++q) {
-        const unsigned long long k = keys[SC_K(base + q)];    // padding keys are all ones: id = SC_NOID
-        W.id[q] = (unsigned)(k >> 32);
-        W.b[q] = (int)(unsigned)k;
-    }
-    W.contL = base > 0 && (unsigned)(keys[SC_K(base - 1)] >> 32) == W.id[0];
-    W.contR = W.count == SC_W && base + SC_W < nb && (unsigned)(keys[SC_K(base + SC_W)] >> 32) == W.id[SC_W - 1];
-}
 // window w is one single run that comes from the left and goes on to the right
-__device__ __forceinline__ bool sc_is_middle(const unsigned long long* keys, int w, int nb) {
+__device__ __forceinline__ bool sc_is_middle(const unsigned* gid, int w, int nb) {
     const int base = w * SC_W;
     if (base + SC_W >= nb) return false;
-    const unsigned a = (unsigned)(keys[SC_K(base)] >> 32);
-    return a == (unsigned)(keys[SC_K(base + SC_W - 1)] >> 32) && a == (unsigned)(keys[SC_K(base + SC_W)] >> 32) &&
-           a == (unsigned)(keys[SC_K(base - 1)] >> 32);
+    const unsigned a = gid[base];
+    return a == gid[base + SC_W - 1] && a == gid[base + SC_W] && a == gid[base - 1];
 }
 
-struct ScSrc {
-    const float* de; const float* dd; const float* dl;
-    long ld_dnn, ld_lin, Btot;
-    int b0, j, D, c0;          // c0: first column of this lane; columns c0 .. c0+3 (those < D are live)
-    bool lin;                  // this lane also carries the linear-table gradient
-    bool dd_vec;               // rows of d_dnn_in are 16-byte aligned (ld_dnn % 4 == 0): float4 loads
-};
-
-// the lane's 5 components of the row gradient of local example bl: d_emb_fm + d_dnn_in (fp32 add, as autograd's
-// accumulation of the two uses of the embedding), and d_lin
-template <int VEC>
-__device__ __forceinline__ void sc_load(const ScSrc& S, int bl, float (&v)[SC_NC]) {
-    const long b = S.b0 + bl;
-    float e[4] = {0.f, 0.f, 0.f, 0.f}, d[4] = {0.f, 0.f, 0.f, 0.f};
-    if (S.c0 < S.D) {
-        if constexpr (VEC == 4) {
-            if (S.de) { const float4 t = *reinterpret_cast<const float4*>(S.de + ((long)S.j * S.Btot + b) * S.D + S.c0); e[0] = t.x; e[1] = t.y; e[2] = t.z; e[3] = t.w; }
-            if (S.dd) {
-                const float* p = S.dd + b * S.ld_dnn + (long)S.j * S.D + S.c0;
-                if (S.dd_vec) { const float4 t = *reinterpret_cast<const float4*>(p); d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w; }
-                else { d[0] = p[0]; d[1] = p[1]; d[2] = p[2]; d[3] = p[3]; }
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (S.c0 + c < S.D) {
-                    if (S.de) e[c] = S.de[((long)S.j * S.Btot + b) * S.D + S.c0 + c];
-                    if (S.dd) d[c] = S.dd[b * S.ld_dnn + (long)S.j * S.D + S.c0 + c];
-                }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = (S.de ? e[c] : 0.f) + (S.dd ? d[c] : 0.f);
-    v[4] = S.lin ? S.dl[b * S.ld_lin] : 0.f;
-}
-
-struct ScDst {
-    float* d_flat; unsigned char* marks;
-    long tab_base, lin_base;   // element offsets of the field's table / linear table in d_flat (-1: absent)
-    int D, c0;
-    bool lin;
-};
-
-// d_flat[row id] += the finished sums of a run (one writer per element: plain read-modify-write)
-template <int VEC>
-__device__ __forceinline__ void sc_store(const ScDst& T, unsigned id, const double (&tot)[SC_NC], const int (&s)[SC_NC]) {
-    float r[SC_NC];
-#pragma unroll
-    for (int c = 0; c < SC_NC; ++c) r[c] = (float)(tot[c] * sc_pow2(-s[c]));
-    if (T.tab_base >= 0 && T.c0 < T.D) {
-        const long e = T.tab_base + (long)id * T.D + T.c0;
-        if (VEC == 4 && (e & 3) == 0) {
-            float4* p = reinterpret_cast<float4*>(T.d_flat + e);
-            float4 o = *p;
-            o.x += r[0]; o.y += r[1]; o.z += r[2]; o.w += r[3];
-            *p = o;
-            if (T.marks) T.marks[e >> 2] = 1;
-        } else {
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (T.c0 + c < T.D) {
-                    T.d_flat[e + c] += r[c];
-                    if (T.marks) T.marks[(e + c) >> 2] = 1;
-                }
-        }
-    }
-    if (T.lin && T.lin_base >= 0) {
-        const long e = T.lin_base + (long)id;
-        T.d_flat[e] += r[4];
-        if (T.marks) T.marks[e >> 2] = 1;
-    }
+// LDS bytes: hash slots (2 per example: key + count) that the window slots reuse, the grouped list, scan scratch
+__host__ __device__ inline size_t sc_lds_bytes(int npad) {
+    const size_t hash = (size_t)2 * npad * 2 * sizeof(unsigned);
+    const size_t slots = (size_t)(npad / SC_W) * SC_NC * (sizeof(double) + sizeof(int));
+    return (hash > slots ? hash : slots) + (size_t)(npad + 8) * (sizeof(unsigned) + sizeof(unsigned short)) + 64 +
+           (size_t)npad * 4 * sizeof(float);                   // + the staged row pieces [npad][4]
 }
 
 template <int VEC>
-__global__ __launch_bounds__(SC_THREADS) void embed_scatter_sorted_kernel(
+__global__ __launch_bounds__(SC_THREADS) void embed_scatter_grouped_kernel(
     const float* __restrict__ X, long ldx, int b0, int nb, long Btot, const int* __restrict__ cols,
     const int* __restrict__ vocab, int m, int D, int nslice, const float* __restrict__ d_emb_fm,
     const float* __restrict__ d_dnn_in, long ld_dnn, const float* __restrict__ d_lin, long ld_lin,
     float* __restrict__ d_flat, const long* __restrict__ tab_off, const long* __restrict__ lin_off,
-    unsigned char* __restrict__ marks, int npad, const int* __restrict__ dense_cols, int nd,
-    float* __restrict__ d_dense_w, long dense_mark_base) {
+    unsigned char* __restrict__ marks, int npad, int nlin, const int* __restrict__ dense_cols, int nd,
+    float* __restrict__ d_dense_w, long dense_mark_base, int dbg) {
+    // dbg: timing experiments only (xdfm option "dbg" bits 12..16; results become wrong): 1 = no grouping,
+    // 2 = no row loads, 4 = no read-modify-writes, 8 = no cross-window phases, 16 = ids without reading X
     extern __shared__ __attribute__((aligned(16))) char sc_smem[];
     const int tid = threadIdx.x;
 
-    if ((int)blockIdx.x >= m * nslice) {
+    if ((int)blockIdx.x >= m * nslice + nlin) {
         // ---- d(linear_model.weight)[k] += sum_b X[b][dense_cols[k]] * d_lin[b]: exact sum of the fp32 products ----
-        const int k = blockIdx.x - m * nslice;
+        const int k = blockIdx.x - m * nslice - nlin;
         const int col = dense_cols[k];
         float* red = reinterpret_cast<float*>(sc_smem);
         double* redd = reinterpret_cast<double*>(sc_smem + 64);
@@ -349,207 +267,344 @@ __global__ __launch_bounds__(SC_THREADS) void embed_scatter_sorted_kernel(
         return;
     }
 
-    const int j = blockIdx.x / nslice, slice = blockIdx.x - j * nslice;
-    const int nwin = npad / SC_W;
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(sc_smem);            // [SC_K(npad + 8) + 1]
-    double* slotF = reinterpret_cast<double*>(sc_smem + sc_keys_bytes(npad));              // [nwin][17]: continuation pieces
-    int* slotO = reinterpret_cast<int*>(slotF + (size_t)nwin * 17);                        // [nwin][17]: owner pieces
-    // ---- S: keys and bitonic sort ------------------------------------------------------------
+    const bool lin = (int)blockIdx.x >= m * nslice;                                        // linear-table workgroup
+    const int j = lin ? (int)blockIdx.x - m * nslice : (int)blockIdx.x / nslice;
+    const int slice = lin ? 0 : (int)blockIdx.x - j * nslice;
+    const int nwin = npad / SC_W;                                                          // <= SC_THREADS
+    const int HS = 2 * npad;                                                               // hash slots (load <= 0.5)
+    unsigned* tkey = reinterpret_cast<unsigned*>(sc_smem);                                 // [HS]
+    unsigned* tcnt = tkey + HS;                                                            // [HS]
+    double* slotF = reinterpret_cast<double*>(sc_smem);                                    // [nwin][4] (after grouping)
+    int* slotO = reinterpret_cast<int*>(slotF + (size_t)nwin * SC_NC);                     // [nwin][4]
+    const size_t hash_b = (size_t)HS * 2 * sizeof(unsigned), slot_b = (size_t)nwin * SC_NC * 12;
+    unsigned* gid = reinterpret_cast<unsigned*>(sc_smem + (hash_b > slot_b ? hash_b : slot_b));   // [npad + 8] grouped ids
+    unsigned short* gb = reinterpret_cast<unsigned short*>(gid + npad + 8);                        // [npad + 8] example in chunk
+    unsigned* wsum = reinterpret_cast<unsigned*>(gb + npad + 8);                                   // [8] scan scratch
+    float4* tile = reinterpret_cast<float4*>(reinterpret_cast<char*>(wsum) + 64);                 // [npad] row pieces by example
+
+    const int c0 = slice * SC_SW;                              // columns c0 .. c0+3 (those < D are live)
+    // Row pieces of the chunk's examples in EXAMPLE order (thread t takes examples t, t + 512, ..): issued first, so
+    // that they are in flight while the ids are grouped; they are parked in LDS afterwards and every window picks its
+    // 8 pieces from there.  d_emb_fm + d_dnn_in is one fp32 add, as autograd's accumulation of the two uses of the
+    // embedding.  Unconditional loads from clamped addresses, masked afterwards.
+    constexpr int KPT = SC_ROWS / SC_THREADS;                  // examples per thread
+    float4 pe[KPT], pd[KPT];
+    {
+        const bool skip = (dbg & 2) != 0;
+#pragma unroll
+        for (int n = 0; n < KPT; ++n) { pe[n] = make_float4(0.f, 0.f, 0.f, 0.f); pd[n] = pe[n]; }
+        if (lin) {
+            if (!skip) {
+#pragma unroll
+                for (int n = 0; n < KPT; ++n) {
+                    const int i = tid + n * SC_THREADS;
+                    pe[n].x = d_lin[(long)(b0 + (i < nb ? i : 0)) * ld_lin];
+                }
+            }
+        } else {
+            if (d_emb_fm && !skip) {
+#pragma unroll
+                for (int n = 0; n < KPT; ++n) {
+                    const int i = tid + n * SC_THREADS;
+                    const float* src = d_emb_fm + ((long)j * Btot + b0 + (i < nb ? i : 0)) * D;
+                    if (VEC == 4) pe[n] = *reinterpret_cast<const float4*>(src + c0);
+                    else pe[n] = make_float4(src[c0 < D ? c0 : D - 1], src[c0 + 1 < D ? c0 + 1 : D - 1],
+                                             src[c0 + 2 < D ? c0 + 2 : D - 1], src[c0 + 3 < D ? c0 + 3 : D - 1]);
+                }
+            }
+            if (d_dnn_in && !skip) {
+#pragma unroll
+                for (int n = 0; n < KPT; ++n) {
+                    const int i = tid + n * SC_THREADS;
+                    const float* src = d_dnn_in + (long)(b0 + (i < nb ? i : 0)) * ld_dnn + (long)j * D;
+                    if (VEC == 4) { const f4u t = *reinterpret_cast<const f4u*>(src + c0); pd[n] = make_float4(t.x, t.y, t.z, t.w); }   // rows are only 4-byte aligned (ld = m*D + nd)
+                    else pd[n] = make_float4(src[c0 < D ? c0 : D - 1], src[c0 + 1 < D ? c0 + 1 : D - 1],
+                                             src[c0 + 2 < D ? c0 + 2 : D - 1], src[c0 + 3 < D ? c0 + 3 : D - 1]);
+                }
+            }
+        }
+    }
+
+    // ---- G: group the examples by id ---------------------------------------------------------------------------
     {
         const int V = vocab[j];
         const int col = cols[j];
-        for (int i = tid; i < npad + 8; i += SC_THREADS) {
-            unsigned long long key = ~0ull;
-            if (i < nb) {
-                long id = (long)X[(long)(b0 + i) * ldx + col];                 // truncation as Tensor.long() (basemodel.py:369)
-                id = id < 0 ? 0 : (id >= V ? V - 1 : id);                      // the gather raised the error flag for these
-                key = ((unsigned long long)id << 32) | (unsigned)i;
+        float xv[KPT];
+#pragma unroll
+        for (int n = 0; n < KPT; ++n) {
+            const int i = tid + n * SC_THREADS;
+            xv[n] = (dbg & 16) ? (float)((i * 7) % V) : X[(long)(b0 + (i < nb ? i : 0)) * ldx + col];
+        }
+        for (int h = tid; h < HS; h += SC_THREADS) { tkey[h] = SC_EMPTY; tcnt[h] = 0; }
+        for (int i = nb + tid; i < npad + 8; i += SC_THREADS) { gid[i] = SC_EMPTY; gb[i] = 0; }
+        __syncthreads();
+        unsigned ids[KPT];
+        int slot[KPT];
+        const int hshift = 32 - (31 - __builtin_clz(HS));
+        unsigned hh[KPT], step[KPT];
+        bool todo[KPT];
+#pragma unroll
+        for (int n = 0; n < KPT; ++n) {
+            const int i = tid + n * SC_THREADS;
+            long id = (long)xv[n];                                     // truncation as Tensor.long() (basemodel.py:369)
+            id = id < 0 ? 0 : (id >= V ? V - 1 : id);                  // the gather raised the error flag for these
+            ids[n] = (unsigned)id;
+            slot[n] = 0;
+            hh[n] = (ids[n] * 2654435761u) >> hshift;
+            step[n] = ((ids[n] * 0x85ebca6bu) >> 15) | 1u;             // double hashing: odd step, HS is a power of two
+            todo[n] = i < nb && !(dbg & 1);
+            if (i < nb && (dbg & 1)) { gid[i] = ids[n]; gb[i] = (unsigned short)i; }
+        }
+        // A slot is claimed by integer compare-and-swap.  Branch-free rounds: the thread's 8 probes are issued
+        // together (8 LDS atomics in flight, one wait); a probe that has found its slot repeats a compare-and-swap that
+        // cannot change anything (its slot already holds its id).  Double hashing: 2-3 rounds on average, the wave
+        // goes on until its slowest lane is done; at most HS rounds.
+        if (!(dbg & 1)) {
+            for (;;) {
+                unsigned prev[KPT];
+#pragma unroll
+                for (int n = 0; n < KPT; ++n) prev[n] = atomicCAS(&tkey[hh[n]], SC_EMPTY, ids[n]);
+                bool any = false;
+#pragma unroll
+                for (int n = 0; n < KPT; ++n) {
+                    const bool ok = prev[n] == SC_EMPTY || prev[n] == ids[n];
+                    hh[n] = ok ? hh[n] : ((hh[n] + step[n]) & (HS - 1));
+                    any = any || !ok;
+                }
+                if (!__any(any)) break;
             }
-            keys[SC_K(i)] = key;
+#pragma unroll
+            for (int n = 0; n < KPT; ++n) {
+                slot[n] = (int)hh[n];
+                atomicAdd(&tcnt[hh[n]], (tid + n * SC_THREADS < nb) ? 1u : 0u);      // an example past the chunk claims nothing
+            }
+        }
+        (void)todo;
+        __syncthreads();
+        if (!(dbg & 1)) {
+            // exclusive scan of the counts over the slots: PER consecutive slots per thread, wave scan, 8 wave totals
+            const int PER = HS >= SC_THREADS ? HS / SC_THREADS : 1;
+            const int s0 = tid * PER;
+            unsigned loc = 0;
+            if (s0 < HS)
+                for (int q = 0; q < PER; ++q) loc += tcnt[s0 + q];
+            unsigned inc = loc;
+            const int lane = tid & 63;
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            if (lane == 63) wsum[tid >> 6] = inc;
+            __syncthreads();
+            unsigned basew = 0;
+            for (int q = 0; q < (tid >> 6); ++q) basew += wsum[q];
+            unsigned run = basew + inc - loc;
+            if (s0 < HS)
+                for (int q = 0; q < PER; ++q) { const unsigned c = tcnt[s0 + q]; tcnt[s0 + q] = run; run += c; }
+            __syncthreads();
+            unsigned pos[KPT];
+#pragma unroll
+            for (int n = 0; n < KPT; ++n) pos[n] = atomicAdd(&tcnt[slot[n]], (tid + n * SC_THREADS < nb) ? 1u : 0u);
+#pragma unroll
+            for (int n = 0; n < KPT; ++n) {
+                const int i = tid + n * SC_THREADS;
+                if (i < nb) { gid[pos[n]] = ids[n]; gb[pos[n]] = (unsigned short)i; }
+            }
         }
         __syncthreads();
-        // levels with compare distance >= 8 through LDS, one barrier each; distances 4, 2, 1 of a merge step inside
-        // one thread's 8 consecutive elements
-        for (int k = 2; k <= npad; k <<= 1) {
-            for (int jj = k >> 1; jj >= 8; jj >>= 1) {
-                for (int t = tid; t < (npad >> 1); t += SC_THREADS) {
-                    const int lo = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), hi = lo | jj;
-                    const bool up = (lo & k) == 0;
-                    const unsigned long long a = keys[SC_K(lo)], b = keys[SC_K(hi)];
-                    if ((a > b) == up) { keys[SC_K(lo)] = b; keys[SC_K(hi)] = a; }
-                }
-                __syncthreads();
-            }
-            for (int blk = tid; blk < (npad >> 3); blk += SC_THREADS) {
-                unsigned long long e[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) e[q] = keys[blk * 9 + q];
-#pragma unroll
-                for (int jj = 4; jj > 0; jj >>= 1) {
-                    if (jj < k) {
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            if ((q & jj) == 0) {
-                                const bool up = ((blk * 8 + q) & k) == 0;
-                                const unsigned long long a = e[q], b = e[q | jj];
-                                const bool sw = (a > b) == up;
-                                e[q] = sw ? b : a;
-                                e[q | jj] = sw ? a : b;
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) keys[blk * 9 + q] = e[q];
-            }
-            __syncthreads();
-        }
     }
 
-    const int grp = tid >> 2, gl = tid & 3;
-    constexpr int NGRP = SC_THREADS / 4;
-    ScSrc S;
-    S.de = d_emb_fm; S.dd = d_dnn_in; S.dl = d_lin; S.ld_dnn = ld_dnn; S.ld_lin = ld_lin; S.Btot = Btot;
-    S.b0 = b0; S.j = j; S.D = D; S.c0 = slice * SC_SW + gl * 4;
-    S.lin = d_lin != nullptr && lin_off != nullptr && slice == 0 && gl == 0;
-    S.dd_vec = d_dnn_in != nullptr && (ld_dnn & 3) == 0 && ((((size_t)d_dnn_in) & 15) == 0);
-    ScDst T;
-    T.d_flat = d_flat; T.marks = marks; T.tab_base = tab_off ? tab_off[j] : -1; T.lin_base = lin_off ? lin_off[j] : -1;
-    T.D = D; T.c0 = S.c0; T.lin = S.lin;
-    const int sl = gl * 4;                                   // this lane's first slot component (component 16 = linear)
+    // ---- this thread's window ----------------------------------------------------------------
+    const int w = tid;
+    const int base = w * SC_W;
+    const bool live = base < nb;
+    const int count = live ? (nb - base < SC_W ? nb - base : SC_W) : 0;
+    unsigned id[SC_W];
+    int bl[SC_W];
+    {
+        const int bs = live ? base : 0;
+        const uint4 i0 = *reinterpret_cast<const uint4*>(gid + bs), i1 = *reinterpret_cast<const uint4*>(gid + bs + 4);
+        const uint4 bb = *reinterpret_cast<const uint4*>(gb + bs);
+        const unsigned iv[8] = {i0.x, i0.y, i0.z, i0.w, i1.x, i1.y, i1.z, i1.w};
+        const unsigned bv[8] = {bb.x & 0xffffu, bb.x >> 16, bb.y & 0xffffu, bb.y >> 16, bb.z & 0xffffu, bb.z >> 16, bb.w & 0xffffu, bb.w >> 16};
+#pragma unroll
+        for (int q = 0; q < SC_W; ++q) {
+            id[q] = live ? iv[q] : SC_EMPTY;
+            bl[q] = q < count ? (int)bv[q] : 0;
+        }
+    }
+    const bool contL = live && base > 0 && gid[base - 1] == id[0];
+    const bool contR = count == SC_W && base + SC_W < nb && gid[base + SC_W] == id[SC_W - 1];
+    const bool single = id[0] == id[SC_W - 1];
+    const bool owner = contR && !(contL && single);            // a run starts here and goes on into the next window
+    // park the row pieces (the loads issued at the top have had the whole grouping phase to land)
+#pragma unroll
+    for (int n = 0; n < KPT; ++n) {
+        const int i = tid + n * SC_THREADS;
+        if (i < npad) tile[i] = make_float4(pe[n].x + pd[n].x, pe[n].y + pd[n].y, pe[n].z + pd[n].z, pe[n].w + pd[n].w);
+    }
+    const bool any_open = __syncthreads_or(contR) != 0;        // also: tile complete; ids read before the slots (same LDS as the hash table) are written
 
-    // ---- 1: every window; closed runs are finished, open pieces leave their maxima in the slots -------------
-    for (int w = grp; w * SC_W < nb; w += NGRP) {
-        ScWin W;
-        sc_window(keys, w, nb, W);
-        float v[SC_W][SC_NC];
+    const long row_base = lin ? (lin_off ? lin_off[j] : -1) : (tab_off ? tab_off[j] : -1);
+    const bool vrow = !lin && VEC == 4 && row_base >= 0 && ((row_base & 3) == 0);
+    // old values of the rows this window may finish: unconditional loads (every id of a live window is a valid row;
+    // dead positions read row 0), issued before the arithmetic so that they are back when the sums are ready
+    float4 old[SC_W];
 #pragma unroll
-        for (int q = 0; q < SC_W; ++q) sc_load<VEC>(S, q < W.count ? W.b[q] : 0, v[q]);
-        // piece maximum of every position: forward then backward over the run structure
-        float pm[SC_W][SC_NC];
+    for (int q = 0; q < SC_W; ++q) old[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row_base >= 0 && !(dbg & 4)) {
+        if (vrow) {
 #pragma unroll
-        for (int q = 0; q < SC_W; ++q)
+            for (int q = 0; q < SC_W; ++q)
+                old[q] = *reinterpret_cast<const float4*>(d_flat + row_base + (long)(q < count ? id[q] : 0u) * D + c0);
+        } else if (lin) {
 #pragma unroll
-            for (int c = 0; c < SC_NC; ++c) {
-                const float a = q < W.count ? fabsf(v[q][c]) : 0.f;
-                pm[q][c] = (q > 0 && W.id[q] == W.id[q - 1]) ? fmaxf(pm[q - 1][c], a) : a;
-            }
+            for (int q = 0; q < SC_W; ++q) old[q].x = d_flat[row_base + (long)(q < count ? id[q] : 0u)];
+        }
+    }
+    float v[SC_W][SC_NC];
 #pragma unroll
-        for (int q = SC_W - 2; q >= 0; --q)
+    for (int q = 0; q < SC_W; ++q) {
+        const float4 t = tile[bl[q]];
+        const float tv[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
-            for (int c = 0; c < SC_NC; ++c)
-                if (q + 1 < W.count && W.id[q] == W.id[q + 1]) pm[q][c] = pm[q + 1][c];
+        for (int c = 0; c < 4; ++c) v[q][c] = (q < count && (lin ? c == 0 : c0 + c < D)) ? tv[c] : 0.f;
+    }
+
+    // ---- 1: piece maxima (forward, then backward over the run structure); closed runs are finished -----------
+    float pm[SC_W][SC_NC];
+#pragma unroll
+    for (int q = 0; q < SC_W; ++q)
+#pragma unroll
+        for (int c = 0; c < SC_NC; ++c) {
+            const float a = fabsf(v[q][c]);
+            pm[q][c] = (q > 0 && id[q] == id[q - 1]) ? fmaxf(pm[q - 1][c], a) : a;
+        }
+#pragma unroll
+    for (int q = SC_W - 2; q >= 0; --q)
+#pragma unroll
+        for (int c = 0; c < SC_NC; ++c)
+            if (q + 1 < count && id[q] == id[q + 1]) pm[q][c] = pm[q + 1][c];
+    float res[SC_W][SC_NC];                     // finished sums, valid where fin[q]
+    bool fin[SC_W];
+    {
         double acc[SC_NC];
 #pragma unroll
         for (int q = 0; q < SC_W; ++q) {
-            if (q < W.count) {
-                const bool first = q == 0 || W.id[q] != W.id[q - 1];
-                const bool last = q == W.count - 1 || W.id[q] != W.id[q + 1];
-                const bool pieceL = W.contL && W.id[q] == W.id[0];
-                const bool pieceR = W.contR && W.id[q] == W.id[SC_W - 1];
-                if (!pieceL && !pieceR) {
-                    int s[SC_NC];
+            const bool first = q == 0 || id[q] != id[q - 1];
+            const bool last = q == count - 1 || (q < count && id[q] != id[q + 1 < SC_W ? q + 1 : q]);
+            const bool pieceL = contL && id[q] == id[0];
+            const bool pieceR = contR && id[q] == id[SC_W - 1];
+            fin[q] = q < count && last && !pieceL && !pieceR && !(dbg & 4);
 #pragma unroll
-                    for (int c = 0; c < SC_NC; ++c) {
-                        s[c] = sc_scale_exp(pm[q][c]);
-                        const double f = sc_fix(v[q][c], sc_pow2(s[c]));
-                        acc[c] = first ? f : acc[c] + f;
-                    }
-                    if (last) sc_store<VEC>(T, W.id[q], acc, s);
-                } else if (last) {
-                    // open piece: its maximum goes to the slot of its kind (a piece open on both sides is a middle one)
+            for (int c = 0; c < SC_NC; ++c) {
+                const int s = sc_scale_exp(pm[q][c]);
+                const double f = sc_fix(v[q][c], sc_pow2(s));
+                acc[c] = first ? f : acc[c] + f;
+                res[q][c] = (float)(acc[c] * sc_pow2(-s));
+            }
+            if (q < count && last && (pieceL || pieceR)) {
+                // open piece: its maximum goes to the slot of its kind (a piece open on both sides is a middle one)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        if (pieceL) reinterpret_cast<float*>(slotF + (size_t)w * 17 + sl + c)[0] = pm[q][c];
-                        else slotO[(size_t)w * 17 + sl + c] = __float_as_int(pm[q][c]);
-                    }
-                    if (S.lin) {
-                        if (pieceL) reinterpret_cast<float*>(slotF + (size_t)w * 17 + 16)[0] = pm[q][4];
-                        else slotO[(size_t)w * 17 + 16] = __float_as_int(pm[q][4]);
-                    }
+                for (int c = 0; c < SC_NC; ++c) {
+                    if (pieceL) reinterpret_cast<float*>(slotF + (size_t)w * SC_NC + c)[0] = pm[q][c];
+                    else slotO[(size_t)w * SC_NC + c] = __float_as_int(pm[q][c]);
                 }
             }
         }
     }
+    // the read-modify-writes of the window (their loads were issued above; one writer per row: no hazard)
+    if (row_base >= 0) {
+#pragma unroll
+        for (int q = 0; q < SC_W; ++q) {
+            if (fin[q]) {
+                if (vrow) {
+                    const long e = row_base + (long)id[q] * D + c0;
+                    *reinterpret_cast<float4*>(d_flat + e) = make_float4(old[q].x + res[q][0], old[q].y + res[q][1],
+                                                                         old[q].z + res[q][2], old[q].w + res[q][3]);
+                    if (marks) marks[e >> 2] = 1;
+                } else if (lin) {
+                    const long e = row_base + (long)id[q];
+                    d_flat[e] = old[q].x + res[q][0];
+                    if (marks) marks[e >> 2] = 1;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c0 + c < D) {
+                            const long e = row_base + (long)id[q] * D + c0 + c;
+                            d_flat[e] += res[q][c];
+                            if (marks) marks[e >> 2] = 1;
+                        }
+                }
+            }
+        }
+    }
+    if (!any_open || (dbg & 8)) return;         // no run crosses a window: done (uniform over the workgroup)
     __syncthreads();
-    // ---- 2: owners (a run that starts in window w and goes on): run maximum -> exponent, handed to every piece ----
-    for (int w = grp; w * SC_W < nb; w += NGRP) {
-        ScWin W;
-        sc_window(keys, w, nb, W);
-        if (!W.contR || (W.contL && W.id[0] == W.id[SC_W - 1])) continue;
+    // ---- 2: owners: run maximum -> exponent, handed to every piece of the run ---------------------------------
+    int so[SC_NC];
+    if (owner) {
         float mx[SC_NC];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mx[c] = __int_as_float(slotO[(size_t)w * 17 + sl + c]);
-        mx[4] = S.lin ? __int_as_float(slotO[(size_t)w * 17 + 16]) : 0.f;
+        for (int c = 0; c < SC_NC; ++c) mx[c] = __int_as_float(slotO[(size_t)w * SC_NC + c]);
         int we = w + 1;
         for (;; ++we) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) mx[c] = fmaxf(mx[c], reinterpret_cast<const float*>(slotF + (size_t)we * 17 + sl + c)[0]);
-            if (S.lin) mx[4] = fmaxf(mx[4], reinterpret_cast<const float*>(slotF + (size_t)we * 17 + 16)[0]);
-            if (!sc_is_middle(keys, we, nb)) break;
+            for (int c = 0; c < SC_NC; ++c) mx[c] = fmaxf(mx[c], reinterpret_cast<const float*>(slotF + (size_t)we * SC_NC + c)[0]);
+            if (!sc_is_middle(gid, we, nb)) break;
         }
-        int s[SC_NC];
 #pragma unroll
-        for (int c = 0; c < SC_NC; ++c) s[c] = sc_scale_exp(mx[c]);
+        for (int c = 0; c < SC_NC; ++c) so[c] = sc_scale_exp(mx[c]);
+        for (int u = w + 1; u <= we; ++u)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) slotO[(size_t)w * 17 + sl + c] = s[c];
-        if (S.lin) slotO[(size_t)w * 17 + 16] = s[4];
-        for (int u = w + 1; u <= we; ++u) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) reinterpret_cast<int*>(slotF + (size_t)u * 17 + sl + c)[0] = s[c];
-            if (S.lin) reinterpret_cast<int*>(slotF + (size_t)u * 17 + 16)[0] = s[4];
-        }
+            for (int c = 0; c < SC_NC; ++c) reinterpret_cast<int*>(slotF + (size_t)u * SC_NC + c)[0] = so[c];
     }
     __syncthreads();
     // ---- 3: continuation pieces: exact partial sums on the run's grid -> slots ----------------------------------
-    for (int w = grp; w * SC_W < nb; w += NGRP) {
-        ScWin W;
-        sc_window(keys, w, nb, W);
-        if (!W.contL) continue;
+    if (contL) {
         int s[SC_NC];
+        double acc[SC_NC];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s[c] = reinterpret_cast<const int*>(slotF + (size_t)w * 17 + sl + c)[0];
-        s[4] = S.lin ? reinterpret_cast<const int*>(slotF + (size_t)w * 17 + 16)[0] : 0;
-        float v[SC_W][SC_NC];
-#pragma unroll
-        for (int q = 0; q < SC_W; ++q) sc_load<VEC>(S, (q < W.count && W.id[q] == W.id[0]) ? W.b[q] : W.b[0], v[q]);
-        double acc[SC_NC] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int c = 0; c < SC_NC; ++c) { s[c] = reinterpret_cast<const int*>(slotF + (size_t)w * SC_NC + c)[0]; acc[c] = 0.0; }
 #pragma unroll
         for (int q = 0; q < SC_W; ++q)
-            if (q < W.count && W.id[q] == W.id[0])
+            if (q < count && id[q] == id[0])
 #pragma unroll
                 for (int c = 0; c < SC_NC; ++c) acc[c] += sc_fix(v[q][c], sc_pow2(s[c]));
 #pragma unroll
-        for (int c = 0; c < 4; ++c) slotF[(size_t)w * 17 + sl + c] = acc[c];
-        if (S.lin) slotF[(size_t)w * 17 + 16] = acc[4];
+        for (int c = 0; c < SC_NC; ++c) slotF[(size_t)w * SC_NC + c] = acc[c];
     }
     __syncthreads();
     // ---- 4: owners: own piece + the partial sums of the windows the run goes through ------------------------------
-    for (int w = grp; w * SC_W < nb; w += NGRP) {
-        ScWin W;
-        sc_window(keys, w, nb, W);
-        if (!W.contR || (W.contL && W.id[0] == W.id[SC_W - 1])) continue;
-        int s[SC_NC];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) s[c] = slotO[(size_t)w * 17 + sl + c];
-        s[4] = S.lin ? slotO[(size_t)w * 17 + 16] : 0;
-        const unsigned rid = W.id[SC_W - 1];
-        float v[SC_W][SC_NC];
-#pragma unroll
-        for (int q = 0; q < SC_W; ++q) sc_load<VEC>(S, W.id[q] == rid ? W.b[q] : W.b[SC_W - 1], v[q]);
-        double acc[SC_NC] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (owner && row_base >= 0) {
+        const unsigned rid = id[SC_W - 1];
+        double acc[SC_NC] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < SC_W; ++q)
-            if (W.id[q] == rid)
+            if (id[q] == rid)
 #pragma unroll
-                for (int c = 0; c < SC_NC; ++c) acc[c] += sc_fix(v[q][c], sc_pow2(s[c]));
+                for (int c = 0; c < SC_NC; ++c) acc[c] += sc_fix(v[q][c], sc_pow2(so[c]));
         for (int we = w + 1;; ++we) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] += slotF[(size_t)we * 17 + sl + c];
-            if (S.lin) acc[4] += slotF[(size_t)we * 17 + 16];
-            if (!sc_is_middle(keys, we, nb)) break;
+            for (int c = 0; c < SC_NC; ++c) acc[c] += slotF[(size_t)we * SC_NC + c];
+            if (!sc_is_middle(gid, we, nb)) break;
         }
-        sc_store<VEC>(T, rid, acc, s);
+        float r[SC_NC];
+#pragma unroll
+        for (int c = 0; c < SC_NC; ++c) r[c] = (float)(acc[c] * sc_pow2(-so[c]));
+        if (lin) {
+            const long e = row_base + (long)rid;
+            d_flat[e] += r[0];
+            if (marks) marks[e >> 2] = 1;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c0 + c < D) {
+                    const long e = row_base + (long)rid * D + c0 + c;
+                    d_flat[e] += r[c];
+                    if (marks) marks[e >> 2] = 1;
+                }
+        }
     }
 }
 
@@ -611,32 +666,35 @@ int xdfm_embed_scatter_bwd_marked(const float* X, long ldx, int B, const int* co
     XDFM_REQUIRE(d_flat || (!tab_off && !lin_off), "embed_scatter_bwd: offsets without a gradient buffer");
     XDFM_REQUIRE(B > 0 && m > 0 && D > 0 && nd >= 0, "embed_scatter_bwd: bad shape");
     hipStream_t st = (hipStream_t)stream;
-    const bool rows = tab_off || (d_lin && lin_off);
+    const bool tabs = tab_off != nullptr;
+    const bool lins = d_lin && lin_off;
     const bool dense = nd > 0 && d_lin && d_dense_w;
     if (dense) XDFM_REQUIRE(dense_cols, "embed_scatter_bwd: dense_cols missing");
-    if (!rows && !dense) return XDFM_OK;
-    XDFM_REQUIRE(!tab_off || d_emb_fm || d_dnn_in, "embed_scatter_bwd: table offsets without row gradients");
-    // float4 path: rows of D floats that start on 16-byte boundaries in every buffer the lanes touch
-    const bool vec4 = D % 4 == 0 && ((((size_t)d_flat) | ((size_t)d_emb_fm)) & 15) == 0;
-    const int nslice = rows ? ceil_div(D, SC_SW) : 0;
+    if (!tabs && !lins && !dense) return XDFM_OK;
+    XDFM_REQUIRE(!tabs || d_emb_fm || d_dnn_in, "embed_scatter_bwd: table offsets without row gradients");
+    // float4 path: rows of D floats that start on 16-byte boundaries in d_flat and d_emb_fm (the kernel checks the
+    // table offsets, which live on the device, lane by lane)
+    const bool vec4 = D % 4 == 0 && ((((size_t)d_flat) | ((size_t)d_emb_fm)) & 15) == 0 && !(xdfm_opt(OPT_DBG) & 2048);
+    const int nslice = tabs ? ceil_div(D, SC_SW) : 0;
+    const int nlin = lins ? m : 0;
     // chunks of SC_ROWS examples, one launch each, in ascending order: a launch owns every row it writes (one
     // workgroup per field and column slice), launches of one stream run in order -- no two writers ever race
     for (long b0 = 0; b0 < B; b0 += SC_ROWS) {
         const int nb = (int)(B - b0 < SC_ROWS ? B - b0 : SC_ROWS);
         int npad = 8;
         while (npad < nb) npad <<= 1;
-        const int nwin = npad / SC_W;
-        const size_t lds = sc_keys_bytes(npad) + (size_t)nwin * 17 * (sizeof(double) + sizeof(int));
-        const dim3 grid(m * nslice + (dense ? nd : 0));
+        const size_t lds = sc_lds_bytes(npad);
+        const dim3 grid(m * nslice + nlin + (dense ? nd : 0));
         const long mark_base = marks && dense ? (long)(d_dense_w - d_flat) : 0L;
+        const int dbg = (xdfm_opt(OPT_DBG) >> 12) & 31;
         if (vec4)
-            hipLaunchKernelGGL((embed_scatter_sorted_kernel<4>), grid, dim3(SC_THREADS), lds, st, X, ldx, (int)b0, nb, (long)B,
+            hipLaunchKernelGGL((embed_scatter_grouped_kernel<4>), grid, dim3(SC_THREADS), lds, st, X, ldx, (int)b0, nb, (long)B,
                                cols, vocab, m, D, nslice, d_emb_fm, d_dnn_in, ld_dnn, d_lin, ld_lin, d_flat, tab_off, lin_off,
-                               marks, npad, dense_cols, dense ? nd : 0, d_dense_w, mark_base);
+                               marks, npad, nlin, dense_cols, dense ? nd : 0, d_dense_w, mark_base, dbg);
         else
-            hipLaunchKernelGGL((embed_scatter_sorted_kernel<1>), grid, dim3(SC_THREADS), lds, st, X, ldx, (int)b0, nb, (long)B,
+            hipLaunchKernelGGL((embed_scatter_grouped_kernel<1>), grid, dim3(SC_THREADS), lds, st, X, ldx, (int)b0, nb, (long)B,
                                cols, vocab, m, D, nslice, d_emb_fm, d_dnn_in, ld_dnn, d_lin, ld_lin, d_flat, tab_off, lin_off,
-                               marks, npad, dense_cols, dense ? nd : 0, d_dense_w, mark_base);
+                               marks, npad, nlin, dense_cols, dense ? nd : 0, d_dense_w, mark_base, dbg);
         const int rc = xdfm_check_launch("embed_scatter_bwd");
         if (rc) return rc;
     }
