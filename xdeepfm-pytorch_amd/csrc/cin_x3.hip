@@ -78,20 +78,22 @@ __device__ __forceinline__ void x3_split_prod2(float a0, float b0, float a1, flo
     lo = __builtin_convertvector(r, h2);
 }
 
-// max_i |col[i * N]| over rows i = first, first + 2, ... < rows, with 8 loads in flight (a one-load-per-iteration
-// loop pays an L2 round trip per row: 64 of them at H = 128)
+// max_i |col[i * N]| over rows i = first, first + 2, ... < rows: 16 unconditional loads in flight per round trip
+// (rows past the end are clamped to a row of the set: harmless for a maximum; more in flight costs the MT = 8
+// kernels registers they do not have).  A loop with a few loads per iteration pays an L2 round trip per iteration.
 __device__ __forceinline__ float x3_col_absmax(const float* __restrict__ col, long N, int first, int rows) {
     float mx = 0.f;
-    int i = first;
-    for (; i + 14 < rows; i += 16) {
-        float v[8];
+    for (int i0 = first; i0 < rows; i0 += 32) {
+        float v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = col[(long)(i + 2 * k) * N];
+        for (int k = 0; k < 16; ++k) {
+            const int i = i0 + 2 * k;
+            v[k] = col[(long)(i < rows ? i : first) * N];
+        }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) mx = fmaxf(mx, fabsf(v[k]));
+        for (int k = 0; k < 16; ++k) mx = fmaxf(mx, fabsf(v[k]));
     }
-    for (; i < rows; i += 2) mx = fmaxf(mx, fabsf(col[(long)i * N]));
-    return mx;
+    return first < rows ? mx : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -183,7 +185,7 @@ __global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, i
 // 32 columns and all MT row tiles.  The packed weight fragments of one step (2*MT KB) are shared by the
 // four waves through a 3-deep LDS ring filled by 16-byte LDS-DMA two steps ahead (one counted
 // s_waitcnt vmcnt + raw s_barrier per step); each wave builds its own B operand (Z hi / lo) in registers.
-template <int MT, int M, int NW>
+template <int MT, int M, int NW, int R = 3>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ pack,
     const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out) {
@@ -201,6 +203,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const long nc = nok ? n : N - 1;
     const float nmask = nok ? 1.f : 0.f;
     const int mb = blockIdx.y;
+    const int dbg = act >> 8;                   // timing experiments (xdfm option "dbg" bits 6..11): 1 no stores, 2 one block, 8 no operand work, 16 no weight DMA
+    act &= 0xff;
 
     const char* wsrc = reinterpret_cast<const char*>(pack + X3_HDR) + (long)mb * (G.NS + 2) * STAGE + lane * 16;
     auto dma_stage = [&](const char* src, int slot_off) {
@@ -211,8 +215,37 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
                                              (LDS_AS void*)(smem + slot_off + f * 1024), 16, 0, 0);
         }
     };
-    dma_stage(wsrc, 0);
-    dma_stage(wsrc + STAGE, STAGE);
+    // x_prev rows of a block (8 rows x the workgroup's 32*NW columns) also arrive by LDS-DMA, one block ahead, into
+    // two buffers behind the ring: per-lane global loads of them made hipcc drain the whole VMEM queue (s_waitcnt
+    // vmcnt(0)) at every block boundary -- the ring's look-ahead with it -- and cost 4 dependent round trips in the
+    // prologue.  4-byte pieces: no alignment requirement on N or xp.
+    constexpr int XCOLS = 32 * NW;              // columns of the workgroup
+    constexpr int XPI = 8 * XCOLS / 64 / NW;    // x_prev DMA instructions per wave and block (256 B each)
+    float* xbuf = reinterpret_cast<float*>(smem + R * STAGE);           // [2][8][XCOLS]
+    float* bias_s = xbuf + 2 * 8 * XCOLS;                               // [32 * MT] bias of the workgroup's rows
+    if ((int)threadIdx.x < 32 * MT) {
+        const int row = blockIdx.y * MT * 32 + threadIdx.x;
+        bias_s[threadIdx.x] = bias[row < H ? row : H - 1];
+    }
+    const long col0 = (long)blockIdx.x * XCOLS;
+    auto dma_xp = [&](int blk, int buf) {
+#pragma unroll
+        for (int k = 0; k < XPI; ++k) {
+            const int e = (wave * XPI + k) * 64;                        // first element of this piece in the [8][XCOLS] tile
+            const int row = e / XCOLS;                                  // wave-uniform
+            int i = blk * 8 + row;
+            i = i < Hp ? i : Hp - 1;                                    // rows past the matrix: any valid row (their factor is 0)
+            long col = col0 + (e - row * XCOLS) + lane;
+            col = col < N ? col : N - 1;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xp + (long)i * N + col),
+                                             (LDS_AS void*)(xbuf + buf * 8 * XCOLS + e), 4, 0, 0);
+        }
+    };
+    dma_xp(0, 0);
+    // the ring runs R - 1 stages ahead of the step being read (R slots); the packed stream ends with 2 spare stages
+    const char* wlast = wsrc + (long)(G.NS + 1) * STAGE;      // last stage that exists (reads past it are clamped to it)
+#pragma unroll
+    for (int k = 0; k < R - 1; ++k) dma_stage(wsrc + (long)(k < G.NS + 2 ? k : G.NS + 1) * STAGE, k * STAGE);
 
     // ---- x0 column (registers), column scales --------------------------------------------------
     float x0r[M];
@@ -239,16 +272,15 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    // x_prev rows of this lane half in block blk: blk*8 + hh*RH + il.  The raw loads are multiplied by
-    // their factor (column scale, or 0 for rows / columns outside the matrix) only where they are first
-    // used, one block later, so nothing waits on them while the ring's DMAs are in flight.
-    auto load_xp = [&](int blk, int RH, float (&v)[4], float (&f)[4]) {
+    // x_prev rows of this lane half in block blk: blk*8 + hh*RH + il, read from the block's LDS buffer and multiplied
+    // by their factor (column scale, or 0 for rows / columns outside the matrix)
+    auto read_xp = [&](int blk, int RH, float (&v)[4]) {
+        const float* xb = xbuf + (blk & 1) * 8 * XCOLS + wave * 32 + c;
 #pragma unroll
         for (int il = 0; il < 4; ++il) {
             const int i = blk * 8 + hh * RH + il;
             const bool ok = il < RH && i < Hp;
-            v[il] = xp[(long)(ok ? i : 0) * N + nc];
-            f[il] = ok ? sp * nmask : 0.f;
+            v[il] = xb[(ok ? hh * RH + il : 0) * XCOLS] * (ok ? sp * nmask : 0.f);
         }
     };
     // B operand (hi, lo) of step s of a block from the block's 4 x_prev values
@@ -264,37 +296,46 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
         }
     };
 
-    int so[3] = {0, STAGE, 2 * STAGE};          // LDS offsets of the ring slots of steps s % 3 of this block
-    const int nblk = G.FB + (G.TS > 0 ? 1 : 0);
-    float xv[4], xn[4], fn[4];
-    load_xp(0, G.FB > 0 ? 4 : G.RH, xv, fn);
+    int so[R];                                  // LDS offsets of the ring slots of steps s % R of this block
 #pragma unroll
-    for (int il = 0; il < 4; ++il) xv[il] *= fn[il];
+    for (int q = 0; q < R; ++q) so[q] = q * STAGE;
+    const int nblk = G.FB + (G.TS > 0 ? 1 : 0);
+    float xv[4], xn[4];
+    // block 0's rows have landed (they were issued before the ring's first stages) for every wave
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * FPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    read_xp(0, G.FB > 0 ? 4 : G.RH, xv);
     h8 bh, bl;
     build_b(0, xv, bh, bl);
     const char* wblk = wsrc;
-
     auto block_steps = [&](int blk, int nsteps_dyn, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const bool has_next = blk + 1 < nblk;
-        if (has_next) load_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn, fn);
 #pragma unroll
         for (int s = 0; s < MP; ++s) {
             if (FULL || s < nsteps_dyn) {       // wave-uniform
             h8 nh = bh, nl = bl;                         // operand of the step after this one, built in its shadow
-            if (s + 1 < MP) {
+            if (dbg & 8) {
+            } else if (s + 1 < MP) {
                 if (FULL || s + 1 < nsteps_dyn) build_b(s + 1, xv, nh, nl);
             } else if (has_next) {
-#pragma unroll
-                for (int il = 0; il < 4; ++il) xn[il] *= fn[il];
+                read_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn);       // landed and published since step R - 1 of this block
                 build_b(0, xn, nh, nl);
             }
-            // stage (blk, s) has landed for this wave's pieces; after the barrier for everyone's
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FPW) : "memory");
+            // stage (blk, s) has landed for this wave's pieces; after the barrier for everyone's.  Younger than its
+            // DMA: the R - 2 stages after it, and in steps 1 .. R-2 of a block the next block's x_prev pieces (issued
+            // in step 0 right after the barrier, before that step's stage)
+            constexpr int AHEAD = R - 2;
+            if (has_next && s >= 1 && s <= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * FPW + XPI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * FPW) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            dma_stage(wblk + (s + 2) * STAGE, so[(s + 2) % 3]);
-            const char* st = smem + so[s % 3] + lane * 16;
+            if (s == 0 && has_next) dma_xp(blk + 1, (blk + 1) & 1);
+            {
+                const char* src = wblk + (long)(s + R - 1) * STAGE;
+                if (!(dbg & 16)) dma_stage(src < wlast ? src : wlast, so[(s + R - 1) % R]);
+            }
+            const char* st = smem + so[s % R] + lane * 16;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const h8 ah = *reinterpret_cast<const h8*>(st + (2 * mt) * 1024);
@@ -309,38 +350,33 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
         // next block: rotate the ring slots by the number of steps taken, first B operand
         const int adv = FULL ? MP : nsteps_dyn;
         wblk += (long)adv * STAGE;
-        for (int k = 0; k < adv % 3; ++k) { const int t = so[0]; so[0] = so[1]; so[1] = so[2]; so[2] = t; }
+        for (int k = 0; k < adv % R; ++k) {
+#pragma unroll
+            for (int q = 0; q + 1 < R; ++q) { const int t = so[q]; so[q] = so[q + 1]; so[q + 1] = t; }
+        }
         if (has_next) {
 #pragma unroll
             for (int il = 0; il < 4; ++il) xv[il] = xn[il];
         }
     };
-    const int dbg = act >> 8;                            // timing experiments only (xdfm option "dbg" bits 6, 7)
-    act &= 0xff;
     for (int blk = 0; blk < ((dbg & 2) ? 1 : G.FB); ++blk) block_steps(blk, MP, std::true_type{});
     if (G.TS > 0) block_steps(G.FB, G.TS, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two look-ahead stages must land before LDS is released
 
     // ---- epilogue: remove the scales, bias + activation, FM-layout store --------------------------
-    // The 16 bias values of a row tile are loaded unconditionally (clamped row) and back to back: behind the
-    // per-row condition hipcc issued them one at a time, an L2 round trip each, 16*MT times per wave.
-    const float iW = pack[1], i0 = 1.f / s0, ip = 1.f / sp;
+    // The bias values of the workgroup's rows sit in LDS since the prologue: their reads count on lgkmcnt, so nothing
+    // makes hipcc put an s_waitcnt vmcnt(0) -- which also waits for the previous STORE -- in front of every store
+    // (with per-row global loads of the bias it did: 16 write round trips per row tile).
+    const float sc = pack[1] * (1.f / sp) * (1.f / s0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        float bv[16];
+        __builtin_amdgcn_sched_barrier(0);          // one row tile at a time: 16 store addresses live, not 16 * MT
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (mb * MT + mt) * 32 + frag_row(r, hh);
-            bv[r] = bias[row < H ? row : H - 1];
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (mb * MT + mt) * 32 + frag_row(r, hh);
-            if (row < H && nok && (!(dbg & 1) || acc[mt][r] == 12345.f)) {
-                float v = acc[mt][r] * iW * ip * i0 + bv[r];
-                if (act == XDFM_ACT_RELU) v = fmaxf(v, 0.f);
-                out[(long)row * N + n] = v;
-            }
+            float v = acc[mt][r] * sc + bias_s[mt * 32 + frag_row(r, hh)];
+            if (act == XDFM_ACT_RELU) v = fmaxf(v, 0.f);
+            if (row < H && nok && (!(dbg & 1) || acc[mt][r] == 12345.f)) out[(long)row * N + n] = v;
         }
     }
 }
@@ -368,19 +404,24 @@ static int launch_x3(const float* xp, const float* x0, const float* pack, const 
                      const X3Geom& g, int act, float* out, hipStream_t st) {
     const size_t lds = (size_t)3 * 2 * MT * 1024;
     constexpr int NWMAX = (2 * MT) % 8 == 0 ? 8 : 4;
-    if (NWMAX == 8 && xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64)
-        hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX>), dim3(ceil_div(N, 32 * NWMAX), g.MB), dim3(64 * NWMAX), lds, st,
-                           xp, x0, pack, bias, H, Hp, N, g, act, out);
-    else
-        hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds, st, xp, x0, pack,
-                           bias, H, Hp, N, g, act, out);
+    if constexpr (NWMAX == 8) {
+        if (xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64) {
+            const dim3 grid(ceil_div(N, 32 * NWMAX), g.MB), block(64 * NWMAX);
+            // ring (weight stages) + bias of the workgroup's rows + two x_prev buffers
+            const size_t ldsx = (size_t)3 * 2 * MT * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
+            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, 3>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
+            return xdfm_check_launch("cin_level_fwd (f16x3)");
+        }
+    }
+    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds + (size_t)2 * 8 * 128 * sizeof(float) + 32 * MT * sizeof(float), st, xp, x0, pack,
+                       bias, H, Hp, N, g, act, out);
     return xdfm_check_launch("cin_level_fwd (f16x3)");
 }
 
 int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
                  int act, float* out, hipStream_t st) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
-    act |= ((xdfm_opt(OPT_DBG) >> 6) & 3) << 8;
+    act |= ((xdfm_opt(OPT_DBG) >> 6) & 255) << 8;     // timing experiments (results become wrong): see the kernels' `dbg`
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd: packed weights must be 16-byte aligned");
 #define X3_CASE(MTV, MV) \
     if (g.MT == MTV && m == MV) return launch_x3<MTV, MV>(xp, x0, pack, bias, H, Hp, N, g, act, out, st);
