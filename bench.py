@@ -42,6 +42,20 @@ CIN_MATH = {0: ("f32mfma", FP32_MFMA_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32 on fp3
                 "peak = dense f16 MFMA peak / 3")}
 HBM_PEAK_GBS = 8000.0
 
+# SURVEY.md 8(d) vocabulary presets.  "criteo-card": the 26 public Criteo-Kaggle cardinalities (C1..C26), all below the
+# 2^24 - 1 limit of ids that travel as fp32 (deepctr/models/basemodel.py:242) -- 33.8 M rows, 574 M parameters; the
+# ids themselves stay synthetic.  "mid": 1e5 rows per field (round 1's bench).  "small": 1e3 (BASELINE config 1).
+CRITEO_CARD = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10,
+               5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+
+
+def preset_vocab(preset, n_sparse):
+    if preset == "criteo-card":
+        if n_sparse != len(CRITEO_CARD):
+            raise SystemExit("the criteo-card preset has %d fields, the workload %d" % (len(CRITEO_CARD), n_sparse))
+        return [min(v, (1 << 24) - 1) for v in CRITEO_CARD]
+    return [{"mid": 100000, "small": 1000}[preset]] * n_sparse
+
 WORKLOADS = {
     # BASELINE.json configs[1]
     "criteo_c2": dict(n_sparse=26, n_dense=13, emb_dim=16, cin=(256, 128, 128), dnn=(256, 256), batch=4096),
@@ -70,14 +84,18 @@ def synthetic_batches(n_batches, batch, vocab, n_dense, seed):
     return out
 
 
-def build_model(cfg, vocab_size, device):
+def build_model(cfg, vocab, device, lazy_rows=False):
     from deepctr.inputs import DenseFeat, SparseFeat
     from deepctr import models
-    cols = [SparseFeat("C%d" % (i + 1), vocab_size, cfg["emb_dim"]) for i in range(cfg["n_sparse"])]
+    cols = [SparseFeat("C%d" % (i + 1), v, cfg["emb_dim"]) for i, v in enumerate(vocab)]
     cols += [DenseFeat("I%d" % (i + 1), 1) for i in range(cfg["n_dense"])]
     cls = getattr(models, cfg.get("model", "xDeepFM"))
     model = cls(cols, cols, dnn_hidden_units=cfg["dnn"], cin_layer_size=cfg["cin"], l2_reg_dnn=1e-5, device=device)
-    model.compile("adam", "binary_crossentropy", metrics=[])
+    if lazy_rows:
+        from xdfm_amd.optim import TableAdam
+        model.compile(TableAdam(model.parameters(), lazy_rows=True), "binary_crossentropy", metrics=[])
+    else:
+        model.compile("adam", "binary_crossentropy", metrics=[])
     return model
 
 
@@ -112,7 +130,7 @@ def log(msg):
 T_START = time.perf_counter()
 
 
-def cpu_baseline(cfg, vocab_size, rows, steps):
+def cpu_baseline(cfg, vocab, rows, steps):
     """The CPU oracle (torch-CPU port of the reference's op sequence) on `rows` rows of the same
     workload: 1 warm-up + up to `steps` timed train steps (stops after ~25 s) on the usable cores."""
     from oracle import xdeepfm_oracle as orc
@@ -121,11 +139,11 @@ def cpu_baseline(cfg, vocab_size, rows, steps):
     names = ["C%d" % (i + 1) for i in range(cfg["n_sparse"])]
     dnames = ["I%d" % (i + 1) for i in range(cfg["n_dense"])]
     variant = {"xDeepFM": "sum", "xDeepFMAttention": "attn", "xDeepFMAttentionV2": "attn_v2"}[cfg.get("model", "xDeepFM")]
-    spec = orc.Spec(names, [vocab_size] * cfg["n_sparse"], dnames, cfg["emb_dim"], tuple(cfg["cin"]), True, "relu",
+    spec = orc.Spec(names, list(vocab), dnames, cfg["emb_dim"], tuple(cfg["cin"]), True, "relu",
                     tuple(cfg["dnn"]), variant, l2_reg_dnn=1e-5)
     state = orc.init_state(spec)
     batches = [(torch.from_numpy(X), torch.from_numpy(y)) for X, y in
-               synthetic_batches(steps + 1, rows, [vocab_size] * cfg["n_sparse"], cfg["n_dense"], seed=7)]
+               synthetic_batches(steps + 1, rows, list(vocab), cfg["n_dense"], seed=7)]
     params = [p.requires_grad_(True) for p in state.values()]
     opt = torch.optim.Adam(params)
 
@@ -177,7 +195,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="criteo_c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--vocab", type=int, default=100000, help="rows per embedding table (SURVEY 8d 'mid' preset)")
+    ap.add_argument("--vocab-preset", default=None, choices=["criteo-card", "mid", "small"],
+                    help="SURVEY 8d vocabulary preset (default: criteo-card for the 26-field workloads, mid otherwise)")
+    ap.add_argument("--vocab", type=int, default=0, help="uniform rows per embedding table (overrides the preset)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the mid-vocabulary and lazy-Adam side measurements")
     ap.add_argument("--cpu-rows", type=int, default=1024)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -190,21 +211,38 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ranks_seen = None
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
+                  % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         n_dev = torch.cuda.device_count()
         local_rank = local_rank % max(n_dev, 1)
         torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-    if args.gpus != world:
-        if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 through torch.distributed.run)"
-                  % (args.gpus, world), file=sys.stderr)
-        sys.exit(2)
+        # fail fast and loudly: RCCL initialisation and one real collective before anything is built or timed
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.backend)
+            probe = torch.ones(1, device=torch.device("cuda", local_rank) if args.backend == "nccl" else "cpu")
+            dist.all_reduce(probe)
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError("all-reduce of ones over %d ranks returned %r" % (world, probe.item()))
+            seen = [None] * world
+            dist.all_gather_object(seen, {"rank": rank, "local_rank": local_rank, "device": torch.cuda.get_device_name(local_rank),
+                                          "pid": os.getpid()})
+            ranks_seen = seen
+        except Exception as exc:      # noqa: BLE001
+            print("bench.py: rank %d: %s backend failed at initialisation / first collective: %r" % (rank, args.backend, exc),
+                  file=sys.stderr, flush=True)
+            sys.exit(3)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -215,16 +253,10 @@ def main():
         _lib.set_option(k, int(v))
     cfg = WORKLOADS[args.workload]
     B = cfg["batch"]
-    log("building model")
-    model = build_model(cfg, args.vocab, device)
-    model.train()
+    preset = args.vocab_preset or ("criteo-card" if cfg["n_sparse"] == len(CRITEO_CARD) else "mid")
+    vocab = [args.vocab] * cfg["n_sparse"] if args.vocab > 0 else preset_vocab(preset, cfg["n_sparse"])
+    vocab_name = ("%d rows/field" % args.vocab) if args.vocab > 0 else preset
     dp = xdist.current()
-    # every rank draws its own resident shard of the global batch (weak scaling: B rows per GPU)
-    n_res = 8
-    batches = [(torch.from_numpy(X).to(device), torch.from_numpy(y).to(device)) for X, y in
-               synthetic_batches(n_res, B, [args.vocab] * cfg["n_sparse"], cfg["n_dense"], seed=2025 + rank)]
-    if dp is not None:
-        dp._n_global = B * world          # the scatter exchange needs the global split (equal shards)
 
     def barrier():
         if world > 1:
@@ -232,54 +264,90 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(steps, warmup, kernel_events=False):
-        """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks.
-        kernel_events: bracket every heavy launch with HIP events on the launch stream (ops.PROFILE); the
-        step then runs from eager launches (events cannot be recorded inside a replayed HIP graph)."""
-        for s in range(warmup):
-            train_step(model, *batches[s % n_res], dp)
-        barrier()
-        ops.PROFILE = [] if kernel_events else None     # (name, flops, start_event, end_event) per heavy launch
-        t0 = time.perf_counter()
-        for s in range(steps):
-            loss = train_step(model, *batches[s % n_res], dp)
-        t_host = time.perf_counter() - t0
-        barrier()
-        dt = time.perf_counter() - t0
-        prof, ops.PROFILE = ops.PROFILE, None
-        if world > 1:
-            import torch.distributed as dist
-            t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        if not np.isfinite(float(loss.item())):
-            raise RuntimeError("non-finite loss in the benchmark loop")
-        return dt, t_host, prof
+    class Run(object):
+        """One model + its resident batches; every rank draws its own shard of the global batch (weak scaling)."""
+
+        def __init__(self, vocab, lazy_rows=False):
+            self.model = build_model(cfg, vocab, device, lazy_rows)
+            self.model.train()
+            self.n_res = 8
+            self.batches = [(torch.from_numpy(X).to(device), torch.from_numpy(y).to(device)) for X, y in
+                            synthetic_batches(self.n_res, B, vocab, cfg["n_dense"], seed=2025 + rank)]
+            if dp is not None:
+                dp._n_global = B * world          # the scatter exchange needs the global split (equal shards)
+            # untimed: the first steps of a batch shape run eagerly and the third one captures the HIP graph the
+            # later steps are replayed from (xdfm_amd/graphstep.py); keep that out of the W + K steps
+            for s in range(4):
+                train_step(self.model, *self.batches[s % self.n_res], dp)
+            self.gstep = self.model.__dict__.get("_graphed_step")
+
+        def timed(self, steps, warmup, kernel_events=False):
+            """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks.
+            kernel_events: bracket every heavy launch with HIP events on the launch stream (ops.PROFILE); the
+            step then runs from eager launches (events cannot be recorded inside a replayed HIP graph)."""
+            for s in range(warmup):
+                train_step(self.model, *self.batches[s % self.n_res], dp)
+            barrier()
+            ops.PROFILE = [] if kernel_events else None     # (name, work, start_event, end_event) per heavy launch
+            t0 = time.perf_counter()
+            for s in range(steps):
+                loss = train_step(self.model, *self.batches[s % self.n_res], dp)
+            t_host = time.perf_counter() - t0
+            barrier()
+            dt = time.perf_counter() - t0
+            prof, ops.PROFILE = ops.PROFILE, None
+            if world > 1:
+                import torch.distributed as dist
+                t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            if not np.isfinite(float(loss.item())):
+                raise RuntimeError("non-finite loss in the benchmark loop")
+            return dt, t_host, prof
 
     math_mode = _lib.get_option("cin_math")
-    # untimed: the first steps of a batch shape run eagerly and the third one captures the HIP graph the
-    # later steps are replayed from (xdfm_amd/graphstep.py); keep that out of the W + K steps
-    for s in range(4):
-        train_step(model, *batches[s % n_res], dp)
-    gstep = model.__dict__.get("_graphed_step")
+    log("building model (vocabulary: %s, %.1f M rows)" % (vocab_name, sum(vocab) / 1e6))
+    run = Run(vocab)
     log("warm-up + timed region (cin_math=%s)" % CIN_MATH[math_mode][0])
-    dt, t_host, _ = timed(args.steps, args.warmup)
-    replayed = gstep is not None and gstep.replays > 0
+    dt, t_host, _ = run.timed(args.steps, args.warmup)
+    replayed = run.gstep is not None and run.gstep.replays > 0
     log("timed region done: %.3f ms/step (host enqueue %.3f ms/step, %s)" % (
         dt / args.steps * 1e3, t_host / args.steps * 1e3,
-        "HIP graph replay, %d nodes" % max(e.nodes for e in gstep.entries.values()) if replayed else "eager launches"))
+        "HIP graph replay, %d nodes" % max(e.nodes for e in run.gstep.entries.values()) if replayed else "eager launches"))
     # per-kernel device times for the roofline: the same steps from eager launches, HIP events around each launch
-    _, _, prof = timed(min(args.steps, 10), 2, kernel_events=True)
+    _, _, prof = run.timed(min(args.steps, 10), 2, kernel_events=True)
     alt = None
     if world == 1 and not args.no_alt:
         # the same K steps with the other arithmetic of the CIN contraction, for reference in the same line
-        other = 1 - math_mode
+        other = 1 - math_mode if math_mode in (0, 1) else 1
         _lib.set_option("cin_math", other)
-        adt, _, _ = timed(args.steps, 4)
+        adt, _, _ = run.timed(args.steps, 4)
         _lib.set_option("cin_math", math_mode)
         alt = dict(cin_math=CIN_MATH[other][0], value=round(B * args.steps / adt, 1), unit="examples/sec",
                    ms_per_step=round(adt / args.steps * 1e3, 4), arithmetic=CIN_MATH[other][2])
         log("other arithmetic (%s): %.3f ms/step" % (CIN_MATH[other][0], adt / args.steps * 1e3))
+    extras = {}
+    if world == 1 and not args.no_extras and args.vocab <= 0 and preset == "criteo-card":
+        # (1) the same step at the mid vocabulary (1e5 rows per field: round 1's headline): what the step costs when the
+        # dense-Adam table sweep is small;  (2) the criteo-card step with the OPT-IN row-sparse ("lazy") Adam, which is
+        # NOT the reference's arithmetic (untouched rows keep their moments): what the sweep costs the reference's way
+        del run.batches
+        run_keep_model = run.model                      # keep alive until the line is printed (state_dict sizes)
+        mid = Run(preset_vocab("mid", cfg["n_sparse"]))
+        mdt, _, _ = mid.timed(args.steps, args.warmup)
+        extras["mid_vocab"] = dict(value=round(B * args.steps / mdt, 1), unit="examples/sec", ms_per_step=round(mdt / args.steps * 1e3, 4),
+                                   vocab="1e5 rows per field (2.6 M rows, 44 M parameters)")
+        log("mid vocabulary: %.3f ms/step" % (mdt / args.steps * 1e3))
+        del mid
+        lazy = Run(vocab, lazy_rows=True)
+        ldt, _, _ = lazy.timed(args.steps, args.warmup)
+        extras["lazy_adam_opt_in"] = dict(
+            value=round(B * args.steps / ldt, 1), unit="examples/sec", ms_per_step=round(ldt / args.steps * 1e3, 4),
+            note="xdfm_amd.optim.TableAdam(lazy_rows=True): rows a batch does not touch are not updated (no moment decay, no L2 "
+                 "pull) -- a deviation from the reference's dense Adam (basemodel.py:452 over sparse=False tables), off by default")
+        log("lazy-Adam opt-in: %.3f ms/step" % (ldt / args.steps * 1e3))
+        del lazy
+        torch.cuda.empty_cache()
 
     if rank == 0:
         # Every step issues the same launch sequence, so launch k of a name is the same kernel on the same shape in
@@ -319,6 +387,7 @@ def main():
                    if k.endswith("[bytes]") else ({} if k.endswith("passes") else {"TFLOPs": round(rate / 1e12, 2)})))
         m_, nd_, D_ = cfg["n_sparse"], cfg["n_dense"], cfg["emb_dim"]
         gather_bytes = 4 * (m_ + nd_) + m_ * (4 * D_ + 4) + 4 * m_ * D_ + 4 * (m_ * D_ + nd_) + 4
+        n_params = sum(p.numel() for p in run.model.parameters())
         out = {
             "metric": "examples/sec (xDeepFM train step, Criteo-shape synthetic, bs=4096 per GPU)",
             "value": round(B * world * args.steps / dt, 1),
@@ -331,11 +400,11 @@ def main():
                              + CIN_MATH[math_mode][2] + (". Error against fp64 <= that of the fp32-MFMA kernels "
                              "(tests/test_gpu_parity.py::test_cin_f16x3_is_as_accurate_as_fp32_mfma); the strict fp32-MFMA "
                              "measurement of the same K steps is `other_arithmetic`" if math_mode == 1 else "")),
-            "config": {"workload": "%s: %d sparse + %d dense, emb_dim %d, cin %s, dnn %s, vocab %d/field, "
-                                   "per-GPU batch %d, Adam + L2, fp32" % (
+            "config": {"workload": "%s: %d sparse + %d dense, emb_dim %d, cin %s, dnn %s, vocabulary %s (%.1f M rows, %.0f M "
+                                   "parameters), per-GPU batch %d, dense Adam + L2 as the reference, fp32" % (
                                        args.workload, cfg["n_sparse"], cfg["n_dense"], cfg["emb_dim"],
-                                       list(cfg["cin"]), list(cfg["dnn"]), args.vocab, B),
-                       "global_batch": B * world, "parallelism": "dp%d" % world},
+                                       list(cfg["cin"]), list(cfg["dnn"]), vocab_name, sum(vocab) / 1e6, n_params / 1e6, B),
+                       "vocab_preset": vocab_name, "global_batch": B * world, "parallelism": "dp%d" % world},
             # the step's throughput against the HBM-gather roofline alone (5 308 algorithmic bytes per
             # example forward at this shape, 8 TB/s): what an embedding-only model could reach per GPU
             "hbm_gather_roofline": {"bytes_per_example": gather_bytes, "bound_examples_per_sec": round(HBM_PEAK_GBS * 1e9 / gather_bytes * world, 1),
@@ -345,10 +414,16 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        out.update(extras)
+        if ranks_seen is not None:
+            out["ranks_seen"] = ranks_seen
+            out["backend"] = args.backend
         if alt is not None:
             out["other_arithmetic"] = alt
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.vocab, args.cpu_rows, args.cpu_steps)
+            if "mid_vocab" in extras:
+                del run                              # the CPU oracle needs the host memory and cores, not the GPU model
+            out["cpu_baseline"] = cpu_baseline(cfg, vocab, args.cpu_rows, args.cpu_steps)
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

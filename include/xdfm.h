@@ -286,7 +286,14 @@ typedef struct {
      * the gradient buffer is all zeros again, ready for the next scatter.  The numel % 4 tail elements are always
      * read and zeroed. */
     unsigned char* grad_marks;
+    /* XDFM_ADAM_LAZY (needs grad_marks): OPT-IN deviation from the reference.  Only marked chunks are updated at all --
+     * an untouched row keeps its weight and moments (no moment decay, no L2 pull) until a batch touches it again, as
+     * in "lazy" / row-sparse Adam; the step's cost then follows the rows a batch touches (plus one mark byte per 16
+     * bytes of table) instead of the vocabulary.  The reference's torch.optim.Adam over dense gradients (deepctr/
+     * inputs.py:168 sparse=False, basemodel.py:452) updates every row every step: 0 keeps that arithmetic. */
+    int flags;
 } xdfm_adam_tensor;
+enum { XDFM_ADAM_LAZY = 1 };
 size_t xdfm_adam_step_ws_elems(int T);
 int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double beta1, double beta2, double eps,
                    float* l2_ws, float* l2_value, void* stream);

@@ -162,3 +162,47 @@ def test_capture_while_an_older_models_graphs_are_being_collected():
     torch.cuda.synchronize()
     assert s2.replays >= 4 and not s2.disabled
     assert np.isfinite(float(out[2]))
+
+
+def test_lazy_rows_opt_in_updates_only_touched_rows():
+    """TableAdam(lazy_rows=True) is an OPT-IN deviation: rows a batch does not touch keep weight and
+    moments; touched rows and all dense weights follow the reference's update.  One step from fresh state: touched
+    rows == dense Adam's, untouched rows == initial values (dense Adam moves them by the L2 term)."""
+    from xdfm_amd.optim import TableAdam
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    dev = _dev()
+    vocab = [500, 400, 300]
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)] + [DenseFeat("I1", 1)]
+
+    def make(lazy):
+        m = xDeepFM(cols, cols, dnn_hidden_units=(16,), cin_layer_size=(8, 4), l2_reg_dnn=1e-5, l2_reg_embedding=1e-2,
+                    init_std=0.1, device=dev)
+        m.compile(TableAdam(m.parameters(), lazy_rows=lazy), "binary_crossentropy", metrics=[])
+        m.train()
+        return m
+
+    rng = np.random.default_rng(3)
+    X = np.concatenate([np.stack([rng.integers(0, 40, 64) for _ in vocab], 1), rng.random((64, 1))], 1).astype(np.float32)
+    y = (rng.random((64, 1)) < 0.5).astype(np.float32)
+    m_lazy, m_dense = make(True), make(False)
+    init = {k: v.detach().cpu().numpy().copy() for k, v in m_lazy.state_dict().items()}
+    for m in (m_lazy, m_dense):
+        m.train_on_batch(T(X).to(dev), T(y).to(dev))
+    torch.cuda.synchronize()
+    sl, sd = m_lazy.state_dict(), m_dense.state_dict()
+    for j, v in enumerate(vocab):
+        rows = np.zeros(v, dtype=bool)
+        rows[X[:, j].astype(int)] = True
+        for key in ("embedding_dict.C%d.weight" % (j + 1), "linear_model.embedding_dict.C%d.weight" % (j + 1)):
+            a, b = sl[key].cpu().numpy(), sd[key].cpu().numpy()
+            touched = rows
+            if a.shape[1] == 1:         # the unit is the 16-byte chunk: 4 neighbouring rows of a [V, 1] table move together
+                touched = np.repeat(rows[:v // 4 * 4].reshape(-1, 4).any(1), 4)
+                touched = np.concatenate([touched, np.full(v - touched.size, rows[v // 4 * 4:].any())])
+            np.testing.assert_allclose(a[touched], b[touched], rtol=1e-5, atol=1e-7, err_msg=key)
+            np.testing.assert_array_equal(a[~touched], init[key][~touched], err_msg=key + " (untouched rows moved)")
+            assert np.abs(b[~touched] - init[key][~touched]).max() > 0       # the reference's dense Adam does move them
+    for key in sl:
+        if "embedding_dict" not in key:
+            np.testing.assert_allclose(sl[key].cpu().numpy(), sd[key].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=key)

@@ -8,13 +8,16 @@ from xdfm_amd import _lib
 lib = _lib.load()
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-V = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+V = sys.argv[2] if len(sys.argv) > 2 else "100000"
 m, D, nd = 26, 16, 13
+CARD = [1460, 583, 10131227, 2202608, 305, 24, 12517, 633, 3, 93145, 5683, 8351593, 3194, 27, 14992, 5461306, 10,
+        5652, 2173, 4, 7046547, 18, 15, 286181, 105, 142572]
+VS = CARD if V == "card" else [int(V)] * m
 rng = np.random.default_rng(0)
 X = np.zeros((B, m + nd), dtype=np.float32)
-X[:, :m] = np.floor(V * rng.random((B, m)) ** 3)
+X[:, :m] = np.floor(np.asarray(VS)[None, :] * rng.random((B, m)) ** 3)
 X[:, m:] = rng.random((B, nd))
-sizes = [V * D] * m + [V] * m
+sizes = [v * D for v in VS] + list(VS)
 offs, off = [], 0
 for n in sizes:
     offs.append(off); off += (n + 3) // 4 * 4
@@ -22,7 +25,7 @@ total = off
 flat = torch.zeros(total + nd + 3, device=dev)
 marks = torch.zeros(flat.numel() // 4 + 2, dtype=torch.uint8, device=dev)
 i32 = dict(dtype=torch.int32, device=dev)
-cols, voc, dcols = torch.arange(m, **i32), torch.tensor([V] * m, **i32), torch.arange(m, m + nd, **i32)
+cols, voc, dcols = torch.arange(m, **i32), torch.tensor(VS, **i32), torch.arange(m, m + nd, **i32)
 off_dev = torch.tensor(offs, dtype=torch.int64, device=dev)
 Xd = torch.from_numpy(X).to(dev)
 de = torch.randn(m, B * D, device=dev); dd = torch.randn(B, m * D + nd, device=dev); dl = torch.randn(B, device=dev)

@@ -77,7 +77,41 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     float4* v4 = reinterpret_cast<float4*>(v);
     float4* g4 = reinterpret_cast<float4*>(g);
     long i = tid;
-    if (marks) {
+    if (marks && (d.flags & XDFM_ADAM_LAZY)) {
+        // opt-in row-sparse update: chunks the batch did not touch are skipped altogether (see xdfm.h)
+        float zf;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
+        const float4 zero4 = make_float4(zf, zf, zf, zf);
+        for (; i + 3 * stride < n4; i += 4 * stride) {            // 4 mark bytes in flight per thread
+            unsigned char k[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) k[q] = marks[i + q * stride];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (k[q]) {
+                    const long e = i + q * stride;
+                    float4 pa = p4[e], ma = m4[e], va = v4[e], ga = g4[e];
+                    g4[e] = zero4; marks[e] = 0;
+                    sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+                    ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+                    adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+                    adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+                    p4[e] = pa; m4[e] = ma; v4[e] = va;
+                }
+            }
+        }
+        for (; i < n4; i += stride) {
+            if (marks[i]) {
+                float4 pa = p4[i], ma = m4[i], va = v4[i], ga = g4[i];
+                g4[i] = zero4; marks[i] = 0;
+                sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+                ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+                adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+                adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+                p4[i] = pa; m4[i] = ma; v4[i] = va;
+            }
+        }
+    } else if (marks) {
         // sparse gradient: a chunk's mark says whether the scatter touched it; unmarked chunks are zeros by
         // construction and are not read, marked ones are read, re-zeroed and unmarked (each lane owns its chunk's
         // mark, so nothing races).  The mark bytes are loaded first, the gradient loads sit behind them.
@@ -185,6 +219,8 @@ int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const d
     for (int t = 0; t < T; ++t)
         XDFM_REQUIRE(tensors[t].param && tensors[t].grad && tensors[t].exp_avg && tensors[t].exp_avg_sq && tensors[t].step &&
                          tensors[t].numel >= 0, "adam_step: tensor %d has a null pointer", t);
+    for (int t = 0; t < T; ++t)
+        XDFM_REQUIRE(!(tensors[t].flags & XDFM_ADAM_LAZY) || tensors[t].grad_marks, "adam_step: tensor %d is lazy but has no grad_marks", t);
     for (int t = 0; t < T; ++t)
         XDFM_REQUIRE(!tensors[t].grad_marks || ((((size_t)tensors[t].param) | ((size_t)tensors[t].grad) | ((size_t)tensors[t].exp_avg) |
                                                   ((size_t)tensors[t].exp_avg_sq)) & 15) == 0,

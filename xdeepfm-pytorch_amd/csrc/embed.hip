@@ -197,18 +197,10 @@ __device__ __forceinline__ int sc_scale_exp(float amax) {
 __device__ __forceinline__ double sc_pow2(int s) { return __longlong_as_double((long long)(1023 + s) << 52); }
 __device__ __forceinline__ double sc_fix(float v, double sc) { return __builtin_rint((double)v * sc); }
 
-// window w is one single run that comes from the left and goes on to the right
-__device__ __forceinline__ bool sc_is_middle(const unsigned* gid, int w, int nb) {
-    const int base = w * SC_W;
-    if (base + SC_W >= nb) return false;
-    const unsigned a = gid[base];
-    return a == gid[base + SC_W - 1] && a == gid[base + SC_W] && a == gid[base - 1];
-}
-
 // LDS bytes: hash slots (2 per example: key + count) that the window slots reuse, the grouped list, scan scratch
 __host__ __device__ inline size_t sc_lds_bytes(int npad) {
     const size_t hash = (size_t)2 * npad * 2 * sizeof(unsigned);
-    const size_t slots = (size_t)(npad / SC_W) * SC_NC * (sizeof(double) + sizeof(int));
+    const size_t slots = (size_t)(npad / SC_W) * 2 * (SC_NC * (sizeof(double) + sizeof(float)) + 2 * sizeof(int));   // open pieces: 2 per window
     return (hash > slots ? hash : slots) + (size_t)(npad + 8) * (sizeof(unsigned) + sizeof(unsigned short)) + 64 +
            (size_t)npad * 4 * sizeof(float);                   // + the staged row pieces [npad][4]
 }
@@ -274,9 +266,13 @@ __global__ __launch_bounds__(SC_THREADS) void embed_scatter_grouped_kernel(
     const int HS = 2 * npad;                                                               // hash slots (load <= 0.5)
     unsigned* tkey = reinterpret_cast<unsigned*>(sc_smem);                                 // [HS]
     unsigned* tcnt = tkey + HS;                                                            // [HS]
-    double* slotF = reinterpret_cast<double*>(sc_smem);                                    // [nwin][4] (after grouping)
-    int* slotO = reinterpret_cast<int*>(slotF + (size_t)nwin * SC_NC);                     // [nwin][4]
-    const size_t hash_b = (size_t)HS * 2 * sizeof(unsigned), slot_b = (size_t)nwin * SC_NC * 12;
+    // after grouping the same LDS holds the OPEN pieces, two elements per window (2w: the window's first piece when it
+    // continues a run from the left; 2w+1: its last piece when the run goes on to the right)
+    double* seqS = reinterpret_cast<double*>(sc_smem);                                     // [2*nwin][4] partial sums
+    float* seqM = reinterpret_cast<float*>(seqS + (size_t)2 * nwin * SC_NC);               // [2*nwin][4] maxima
+    int* seqN = reinterpret_cast<int*>(seqM + (size_t)2 * nwin * SC_NC);                   // [2*nwin] next element of the run, -1 = last
+    int* seqH = seqN + 2 * nwin;                                                           // [2*nwin] head element of the run
+    const size_t hash_b = (size_t)HS * 2 * sizeof(unsigned), slot_b = (size_t)nwin * 2 * (SC_NC * 12 + 8);
     unsigned* gid = reinterpret_cast<unsigned*>(sc_smem + (hash_b > slot_b ? hash_b : slot_b));   // [npad + 8] grouped ids
     unsigned short* gb = reinterpret_cast<unsigned short*>(gid + npad + 8);                        // [npad + 8] example in chunk
     unsigned* wsum = reinterpret_cast<unsigned*>(gb + npad + 8);                                   // [8] scan scratch
@@ -503,13 +499,10 @@ __global__ __launch_bounds__(SC_THREADS) void embed_scatter_grouped_kernel(
                 acc[c] = first ? f : acc[c] + f;
                 res[q][c] = (float)(acc[c] * sc_pow2(-s));
             }
-            if (q < count && last && (pieceL || pieceR)) {
-                // open piece: its maximum goes to the slot of its kind (a piece open on both sides is a middle one)
+            if (any_open && q < count && last && (pieceL || pieceR)) {
+                // open piece: its maximum goes to its element (a piece open on both sides uses the window's first element)
 #pragma unroll
-                for (int c = 0; c < SC_NC; ++c) {
-                    if (pieceL) reinterpret_cast<float*>(slotF + (size_t)w * SC_NC + c)[0] = pm[q][c];
-                    else slotO[(size_t)w * SC_NC + c] = __float_as_int(pm[q][c]);
-                }
+                for (int c = 0; c < SC_NC; ++c) seqM[(size_t)(2 * w + (pieceL ? 0 : 1)) * SC_NC + c] = pm[q][c];
             }
         }
     }
@@ -540,58 +533,105 @@ __global__ __launch_bounds__(SC_THREADS) void embed_scatter_grouped_kernel(
         }
     }
     if (!any_open || (dbg & 8)) return;         // no run crosses a window: done (uniform over the workgroup)
+    // ---- 2-4: runs that cross windows, in parallel over their pieces -----------------------------------------------
+    // A run's open pieces form a chain of elements e -> seqN[e]: (2w+1) -> 2(w+1) when the run leaves window w, and
+    // 2w -> 2w+1 inside a window that is one single run passing through.  Pointer jumping (log2 of the longest chain
+    // rounds, all chains at once) gives every piece the run's maximum -- hence its grid -- and then the head of the
+    // chain, which is the window where the run starts, the exact sum of the pieces.  (A serial walk by the owner cost
+    // 150 us on a field with 3 ids: runs of 3000 examples = 350 windows.)
+    const bool both = contL && contR && single;              // one piece, open on both sides: element 2w, linked to 2w+1
+    const bool act = w < nwin;                               // threads past the chunk's windows own no elements
+    const int e0 = act ? 2 * w : 0, e1 = act ? 2 * w + 1 : 0;
+    if (act) {
+        const bool hasL = live && contL, hasR = live && contR && !both;
+        if (!hasL) {
+#pragma unroll
+            for (int c = 0; c < SC_NC; ++c) seqM[(size_t)e0 * SC_NC + c] = 0.f;
+        }
+        if (!hasR) {
+#pragma unroll
+            for (int c = 0; c < SC_NC; ++c) seqM[(size_t)e1 * SC_NC + c] = 0.f;
+        }
+        seqN[e0] = both ? e1 : -1;
+        seqN[e1] = (live && contR) ? e1 + 1 : -1;
+        // head pointers start at the left neighbour in the chain (or at the element itself: a head)
+        seqH[e0] = (live && contL) ? e0 - 1 : e0;
+        seqH[e1] = both ? e0 : e1;
+    }
     __syncthreads();
-    // ---- 2: owners: run maximum -> exponent, handed to every piece of the run ---------------------------------
-    int so[SC_NC];
-    if (owner) {
-        float mx[SC_NC];
+    // suffix maxima along the chains + head of every element, by pointer jumping (reads, barrier, writes, barrier);
+    // one 16-byte LDS access per element (scalar accesses at this stride are 8-way bank conflicts)
+    float4* seqM4 = reinterpret_cast<float4*>(seqM);
+    for (;;) {
+        const int n0 = act ? seqN[e0] : -1, n1 = act ? seqN[e1] : -1, h0 = seqH[e0], h1 = seqH[e1];
+        const int nn0 = n0 >= 0 ? seqN[n0] : -1, nn1 = n1 >= 0 ? seqN[n1] : -1;
+        const int hh0 = seqH[h0], hh1 = seqH[h1];
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 m0 = n0 >= 0 ? seqM4[n0] : z4, m1 = n1 >= 0 ? seqM4[n1] : z4;
+        const float4 o0 = seqM4[e0], o1 = seqM4[e1];
+        const bool more = act && (n0 >= 0 || n1 >= 0 || hh0 != h0 || hh1 != h1);
+        if (!__syncthreads_or(more)) break;
+        if (act) {
+            seqM4[e0] = make_float4(fmaxf(o0.x, m0.x), fmaxf(o0.y, m0.y), fmaxf(o0.z, m0.z), fmaxf(o0.w, m0.w));
+            seqM4[e1] = make_float4(fmaxf(o1.x, m1.x), fmaxf(o1.y, m1.y), fmaxf(o1.z, m1.z), fmaxf(o1.w, m1.w));
+            seqN[e0] = nn0; seqN[e1] = nn1; seqH[e0] = hh0; seqH[e1] = hh1;
+        }
+        __syncthreads();
+    }
+    // every open piece: the run's grid from the maximum at the chain's head; exact partial sum of the piece
+    int sL[SC_NC], sR[SC_NC];
+    {
+        const int h0 = seqH[e0], h1 = seqH[e1];
+        double aL[SC_NC], aR[SC_NC];
 #pragma unroll
-        for (int c = 0; c < SC_NC; ++c) mx[c] = __int_as_float(slotO[(size_t)w * SC_NC + c]);
-        int we = w + 1;
-        for (;; ++we) {
-#pragma unroll
-            for (int c = 0; c < SC_NC; ++c) mx[c] = fmaxf(mx[c], reinterpret_cast<const float*>(slotF + (size_t)we * SC_NC + c)[0]);
-            if (!sc_is_middle(gid, we, nb)) break;
+        for (int c = 0; c < SC_NC; ++c) {
+            sL[c] = sc_scale_exp(seqM[(size_t)h0 * SC_NC + c]);
+            sR[c] = sc_scale_exp(seqM[(size_t)h1 * SC_NC + c]);
+            aL[c] = 0.0; aR[c] = 0.0;
         }
 #pragma unroll
-        for (int c = 0; c < SC_NC; ++c) so[c] = sc_scale_exp(mx[c]);
-        for (int u = w + 1; u <= we; ++u)
+        for (int q = 0; q < SC_W; ++q) {
+            const bool inL = contL && q < count && id[q] == id[0];
+            const bool inR = contR && !both && id[q] == id[SC_W - 1];
 #pragma unroll
-            for (int c = 0; c < SC_NC; ++c) reinterpret_cast<int*>(slotF + (size_t)u * SC_NC + c)[0] = so[c];
+            for (int c = 0; c < SC_NC; ++c) {
+                if (inL) aL[c] += sc_fix(v[q][c], sc_pow2(sL[c]));
+                if (inR) aR[c] += sc_fix(v[q][c], sc_pow2(sR[c]));
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int c = 0; c < SC_NC; ++c) {
+                seqS[(size_t)e0 * SC_NC + c] = aL[c];
+                seqS[(size_t)e1 * SC_NC + c] = aR[c];
+            }
+            seqN[e0] = both ? e1 : -1;                       // the chains again (the jumping above consumed them)
+            seqN[e1] = (live && contR) ? e1 + 1 : -1;
+        }
     }
     __syncthreads();
-    // ---- 3: continuation pieces: exact partial sums on the run's grid -> slots ----------------------------------
-    if (contL) {
-        int s[SC_NC];
-        double acc[SC_NC];
-#pragma unroll
-        for (int c = 0; c < SC_NC; ++c) { s[c] = reinterpret_cast<const int*>(slotF + (size_t)w * SC_NC + c)[0]; acc[c] = 0.0; }
-#pragma unroll
-        for (int q = 0; q < SC_W; ++q)
-            if (q < count && id[q] == id[0])
-#pragma unroll
-                for (int c = 0; c < SC_NC; ++c) acc[c] += sc_fix(v[q][c], sc_pow2(s[c]));
-#pragma unroll
-        for (int c = 0; c < SC_NC; ++c) slotF[(size_t)w * SC_NC + c] = acc[c];
+    double2* seqS2 = reinterpret_cast<double2*>(seqS);
+    for (;;) {                                                // suffix sums along the chains: integer-valued doubles, exact
+        const int n0 = act ? seqN[e0] : -1, n1 = act ? seqN[e1] : -1;
+        const int nn0 = n0 >= 0 ? seqN[n0] : -1, nn1 = n1 >= 0 ? seqN[n1] : -1;
+        const double2 z2 = make_double2(0.0, 0.0);
+        const double2 a0l = n0 >= 0 ? seqS2[2 * n0] : z2, a0h = n0 >= 0 ? seqS2[2 * n0 + 1] : z2;
+        const double2 a1l = n1 >= 0 ? seqS2[2 * n1] : z2, a1h = n1 >= 0 ? seqS2[2 * n1 + 1] : z2;
+        const double2 o0l = seqS2[2 * e0], o0h = seqS2[2 * e0 + 1], o1l = seqS2[2 * e1], o1h = seqS2[2 * e1 + 1];
+        if (!__syncthreads_or(n0 >= 0 || n1 >= 0)) break;
+        if (act) {
+            seqS2[2 * e0] = make_double2(o0l.x + a0l.x, o0l.y + a0l.y); seqS2[2 * e0 + 1] = make_double2(o0h.x + a0h.x, o0h.y + a0h.y);
+            seqS2[2 * e1] = make_double2(o1l.x + a1l.x, o1l.y + a1l.y); seqS2[2 * e1 + 1] = make_double2(o1h.x + a1h.x, o1h.y + a1h.y);
+            seqN[e0] = nn0; seqN[e1] = nn1;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // ---- 4: owners: own piece + the partial sums of the windows the run goes through ------------------------------
+    // the head of a chain is the last piece of the window where the run starts: it writes the row
     if (owner && row_base >= 0) {
         const unsigned rid = id[SC_W - 1];
-        double acc[SC_NC] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < SC_W; ++q)
-            if (id[q] == rid)
-#pragma unroll
-                for (int c = 0; c < SC_NC; ++c) acc[c] += sc_fix(v[q][c], sc_pow2(so[c]));
-        for (int we = w + 1;; ++we) {
-#pragma unroll
-            for (int c = 0; c < SC_NC; ++c) acc[c] += slotF[(size_t)we * SC_NC + c];
-            if (!sc_is_middle(gid, we, nb)) break;
-        }
         float r[SC_NC];
 #pragma unroll
-        for (int c = 0; c < SC_NC; ++c) r[c] = (float)(acc[c] * sc_pow2(-so[c]));
+        for (int c = 0; c < SC_NC; ++c) r[c] = (float)(seqS[(size_t)e1 * SC_NC + c] * sc_pow2(-sR[c]));
         if (lin) {
             const long e = row_base + (long)rid;
             d_flat[e] += r[0];

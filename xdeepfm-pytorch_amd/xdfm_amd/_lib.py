@@ -66,7 +66,7 @@ class PackJob(ctypes.Structure):
 class AdamTensor(ctypes.Structure):
     """xdfm_adam_tensor of include/xdfm.h"""
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
-                ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float), ("grad_marks", c_void_p)]
+                ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float), ("grad_marks", c_void_p), ("flags", c_int)]
 
 
 ABI_VERSION = 4

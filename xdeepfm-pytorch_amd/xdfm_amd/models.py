@@ -515,6 +515,9 @@ class BaseModel(nn.Module):
         self.metrics_names = ["loss"]
         self._optim_capturable = False
         self.optim = self._get_optim(optimizer)
+        from .optim import TableAdam
+        if isinstance(self.optim, TableAdam):          # also when handed in as an object, e.g. TableAdam(..., lazy_rows=True)
+            self._optim_capturable = all(p.is_cuda for g in self.optim.param_groups for p in g["params"])
         self.loss_func = self._get_loss_func(loss)
         self.metrics = self._get_metrics(metrics)
 

@@ -21,8 +21,13 @@ from . import _lib
 
 
 class TableAdam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lazy_rows=False):
         super().__init__(params, lr=lr, betas=betas, eps=eps, fused=True, capturable=True)
+        # OPT-IN deviation from the reference: rows of the embedding tables that a batch does not touch
+        # are not updated at all (no moment decay, no L2 pull) -- "lazy" Adam.  The reference's dense Adam updates every
+        # row every step; with `lazy_rows` the step's cost follows the batch instead of the vocabulary.  Applies only to
+        # gradients that arrive through the kept, marked gradient buffer (the model's own train step).
+        self.lazy_rows = bool(lazy_rows)
         self._armed = None          # id(parameter) -> L2 strength, for the next step only
         self._desc = {}             # group index -> (key, ctypes array of xdfm_adam_tensor)
         self.l2_value = None        # [1] device tensor: value of the armed L2 term at the last step
@@ -74,6 +79,7 @@ class TableAdam(torch.optim.Adam):
         for k in ("_desc", "_lr_dev", "_armed", "l2_value"):      # ctypes descriptors / device scalars: rebuilt on use
             state[k] = {} if k in ("_desc", "_lr_dev") else None
         state["grad_sources"] = []
+        state["lazy_rows"] = self.lazy_rows
         return state
 
     def __setstate__(self, state):
@@ -83,6 +89,7 @@ class TableAdam(torch.optim.Adam):
         self.__dict__.setdefault("_armed", None)
         self.__dict__.setdefault("l2_value", None)
         self.__dict__.setdefault("grad_sources", [])
+        self.__dict__.setdefault("lazy_rows", False)
         self.generation = self.__dict__.get("generation", 0) + 1
 
     def owns(self, tensors):
@@ -150,11 +157,12 @@ class TableAdam(torch.optim.Adam):
             arenas = [a for src in self.grad_sources for a in src.arenas() if a.pending]
             for k in range(T):
                 gp = grads[k].data_ptr()
-                arr[k].grad, arr[k].grad_marks = gp, None
+                arr[k].grad, arr[k].grad_marks, arr[k].flags = gp, None, 0
                 for a in arenas:                       # a view of a kept gradient buffer: read it by its marks
                     mp = a.marks_ptr(gp)
                     if mp is not None and params[k].data_ptr() % 16 == 0:
                         arr[k].grad_marks = mp
+                        arr[k].flags = 1 if (self.lazy_rows and params[k].dim() == 2 and params[k].shape[0] > 1) else 0
                         a.consumed(gp)
                         break
             torch._foreach_add_(steps, 1)
@@ -165,10 +173,12 @@ class TableAdam(torch.optim.Adam):
                 val = torch.empty(1, dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             lr_dev = self._lr_dev.get(gi)
-            _lib.check(lib.xdfm_adam_step_lr(ctypes.cast(arr, ctypes.c_void_p), T, float(group["lr"]),
+            from . import ops                          # per-kernel timing hook of bench.py (HIP events on the launch stream)
+            nbytes = sum(params[k].numel() * (24.25 if arr[k].grad_marks else 28.0) for k in range(T))
+            _lib.check(ops._run("adam_step[bytes]", nbytes, lambda: lib.xdfm_adam_step_lr(ctypes.cast(arr, ctypes.c_void_p), T, float(group["lr"]),
                                              lr_dev[1].data_ptr() if lr_dev is not None else None, float(beta1),
                                              float(beta2), float(group["eps"]), ws.data_ptr() if ws is not None else None,
-                                             val.data_ptr() if val is not None else None, stream), "adam_step")
+                                             val.data_ptr() if val is not None else None, stream)), "adam_step")
             if val is not None:
                 self.l2_value = val if self.l2_value is None else self.l2_value + val
         return None
