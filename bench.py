@@ -39,7 +39,10 @@ F16_MFMA_PEAK_TFLOPS = 2516.6      # dense f16/bf16 MFMA: 256 CU x 4 SIMD x 1024
 CIN_MATH = {0: ("f32mfma", FP32_MFMA_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32 on fp32 operands"),
             1: ("f16x3", F16_MFMA_PEAK_TFLOPS / 3.0,
                 "fp32 operands split into fp16 hi+lo, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulate; "
-                "peak = dense f16 MFMA peak / 3")}
+                "peak = dense f16 MFMA peak / 3"),
+            2: ("bf16", F16_MFMA_PEAK_TFLOPS,
+                "operands rounded to bf16, 1 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (BASELINE config 5's "
+                "arithmetic; tolerance 2e-2 / 4e-2 of a tensor's largest magnitude, tests/test_gpu_parity.py)")}
 HBM_PEAK_GBS = 8000.0
 
 # SURVEY.md 8(d) vocabulary presets.  "criteo-card": the 26 public Criteo-Kaggle cardinalities (C1..C26), all below the
@@ -62,8 +65,8 @@ WORKLOADS = {
     # BASELINE.json configs[0] (CPU plumbing shape), handy for quick runs
     "criteo_c1": dict(n_sparse=26, n_dense=13, emb_dim=8, cin=(128, 128), dnn=(256, 256), batch=4096),
     # BASELINE.json configs[2]: xDeepFMAttention, same Criteo shape (script-default cin (256,128) -> 256 tokens)
-    # BASELINE.json configs[4] shape on one GPU: Avazu (22 sparse fields, no dense), emb_dim 32, deep CIN.  The config
-    # names a bf16 MFMA path; here it runs the default f16x3 arithmetic (fp32 accuracy at the f16 pipe's rate).
+    # BASELINE.json configs[4] shape on one GPU: Avazu (22 sparse fields, no dense), emb_dim 32, deep CIN, in the bf16
+    # MFMA arithmetic the config names (cin_math 2; --cin-math 1 runs it in f16x3)
     "avazu_c5": dict(n_sparse=22, n_dense=0, emb_dim=32, cin=(512, 256, 256, 128), dnn=(256, 256), batch=4096),
     "criteo_c3_attn": dict(n_sparse=26, n_dense=13, emb_dim=16, cin=(256, 128), dnn=(256, 256), batch=4096,
                            model="xDeepFMAttention"),
@@ -204,6 +207,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the second timed region with the other CIN arithmetic")
     ap.add_argument("--option", action="append", default=[], help="libxdfm tuning knob key=value")
+    ap.add_argument("--cin-math", type=int, default=None, choices=[0, 1, 2],
+                    help="CIN arithmetic: 0 fp32 MFMA, 1 f16x3 (default), 2 bf16 (default for --workload avazu_c5)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only "
                     "to rehearse the multi-rank path with several ranks on one GPU)")
     args = ap.parse_args()
@@ -253,6 +258,8 @@ def main():
         _lib.set_option(k, int(v))
     cfg = WORKLOADS[args.workload]
     B = cfg["batch"]
+    if args.cin_math is not None or args.workload == "avazu_c5":
+        _lib.set_option("cin_math", args.cin_math if args.cin_math is not None else 2)    # config 5 names the bf16 MFMA path
     preset = args.vocab_preset or ("criteo-card" if cfg["n_sparse"] == len(CRITEO_CARD) else "mid")
     vocab = [args.vocab] * cfg["n_sparse"] if args.vocab > 0 else preset_vocab(preset, cfg["n_sparse"])
     vocab_name = ("%d rows/field" % args.vocab) if args.vocab > 0 else preset
@@ -319,7 +326,7 @@ def main():
     alt = None
     if world == 1 and not args.no_alt:
         # the same K steps with the other arithmetic of the CIN contraction, for reference in the same line
-        other = 1 - math_mode if math_mode in (0, 1) else 1
+        other = 1 - math_mode if math_mode in (0, 1) else 1          # beside bf16: the f16x3 (fp32-grade) measurement
         _lib.set_option("cin_math", other)
         adt, _, _ = run.timed(args.steps, 4)
         _lib.set_option("cin_math", math_mode)
@@ -395,7 +402,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if math_mode == 2 else "f32", "data": "synthetic",
             "dtype_detail": ("fp32 inputs, weights, accumulators, outputs and optimizer state in both CIN arithmetics; "
                              + CIN_MATH[math_mode][2] + (". Error against fp64 <= that of the fp32-MFMA kernels "
                              "(tests/test_gpu_parity.py::test_cin_f16x3_is_as_accurate_as_fp32_mfma); the strict fp32-MFMA "

@@ -18,7 +18,8 @@
  *     wavefront read consecutive n and one example's D values are contiguous.
  *   - operands, accumulators and results are IEEE fp32 ("dtype f32").  The CIN contractions run either on
  *     v_mfma_f32_32x32x2_f32 or, by default, as three v_mfma_f32_32x32x16_f16 per fp32 product on operands
- *     split into fp16 hi + lo halves with fp32 accumulation (option "cin_math", see xdfm_set_option);
+ *     split into fp16 hi + lo halves with fp32 accumulation, or (opt-in) as one v_mfma_f32_32x32x16_bf16 on operands
+ *     rounded to bf16 (option "cin_math", see xdfm_set_option);
  *   - nothing in the library issues a memset (hipMemsetAsync nodes inside a captured graph are not ordered
  *     reliably on ROCm 7.2 / gfx950); reductions use per-block partials and fixed-order finish kernels.
  *
@@ -61,7 +62,12 @@ int xdfm_device_count(void);                /* <0: HIP error code negated */
  *      power-of-two range fitting) and each product is three v_mfma_f32_32x32x16_f16 accumulated in fp32;
  *      error against an fp64 evaluation <= that of mode 0 (tests/test_gpu_parity.py); shapes without an
  *      f16x3 kernel (odd field counts in the forward, H <= 64 in dW, ...) run mode 0 kernels;
- *   0 "f32mfma": v_mfma_f32_32x32x2_f32 on the fp32 operands. */
+ *   0 "f32mfma": v_mfma_f32_32x32x2_f32 on the fp32 operands;
+ *   2 "bf16" (BASELINE config 5's arithmetic): operands rounded to bf16 (RNE), ONE v_mfma_f32_32x32x16_bf16 per
+ *      product, fp32 accumulation, fp32 results; no range fitting (bf16 has fp32's exponent range).  Its tolerance is
+ *      its own: 2e-2 (outputs) / 4e-2 (gradients) of a tensor's largest magnitude against the fp32 reference,
+ *      measured 3e-3 / 8e-3 (tests/test_gpu_parity.py::test_cin_bf16_mfma_path_vs_fp32_oracle).  Kernels exist for
+ *      H > 64 (forward, dW), 32 < H <= 256 per call (dX), m in {22, 26}; other shapes run mode 0. */
 /* read-only probes (xdfm_get_option): "last_fwd_kernel", "last_bwx_kernel", "last_bww_kernel" = arithmetic of the kernel
  * the last xdfm_cin_level_fwd / _bwd_x / _bwd_w call launched (0 f32mfma, 1 f16x3, 2 bf16; -1 before the first call):
  * a shape without a kernel in the selected mode runs mode 0, and the tests assert which one ran. */

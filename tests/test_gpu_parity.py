@@ -116,6 +116,97 @@ def test_cin_vs_oracle_random(B, m, D, ls, cin_math):
             gclose(c.bias.grad, Bs[i].grad.numpy(), "db%d" % i)
 
 
+@pytest.mark.parametrize("B,m,D,ls,act", [
+    (96, 22, 32, (512, 256, 256, 128), "linear"),      # BASELINE config 5 layer sizes (Avazu shape), gradients checked
+    (96, 22, 32, (512, 256, 256, 128), "relu"),
+    (130, 26, 16, (256, 128, 128), "linear"),          # config 2 layer sizes
+    (64, 26, 16, (256, 128, 128), "relu"),
+])
+def test_cin_bf16_mfma_path_vs_fp32_oracle(B, m, D, ls, act):
+    """cin_math = 2 (BASELINE config 5, "bf16 MFMA path"): operands rounded to bf16 (RNE), ONE v_mfma_f32_32x32x16_bf16
+    per product, fp32 accumulation, fp32 results; no range fitting (bf16 has fp32's exponent).  Tolerance of this
+    arithmetic, stated here: every product carries two 2^-9 roundings, so outputs and gradients are compared with the
+    fp32 oracle (deepctr/layers/interaction.py:218-246 on the CPU) to 2e-2 / 4e-2 of the tensor's largest magnitude
+    (measured: 3e-3 / 8e-3), three orders looser than the 1e-5-grade fp32 modes -- SURVEY 7-3 expects 7e-4..3e-3 on the
+    CIN output.  With ReLU a pre-activation within that error of zero may switch on one side only, so the gradients
+    of the ReLU cases are compared by direction (cosine > 0.999) and the element-wise check uses the linear cases."""
+    from deepctr.layers import CIN
+    from oracle import xdeepfm_oracle as orc
+    from xdfm_amd import _lib
+    dev = _dev()
+    old = _lib.get_option("cin_math")
+    _lib.set_option("cin_math", 2)
+    try:
+        torch.manual_seed(B + m)
+        layer = CIN(m, ls, act, True, 0.0, 1024, device="cpu")
+        x = (torch.randn(B, m, D) * 0.5).requires_grad_(True)
+        W = [c.weight.detach().clone().requires_grad_(True) for c in layer.conv1ds]
+        Bs = [c.bias.detach().clone().requires_grad_(True) for c in layer.conv1ds]
+        want = orc.cin_forward(x, W, Bs, True, act)
+        gout = torch.randn(want.shape)
+        (want * gout).sum().backward()
+        layer = layer.to(dev)
+        xg = x.detach().to(dev).requires_grad_(True)
+        out = layer(xg)
+        assert _lib.get_option("last_fwd_kernel") == 2          # the bf16 kernel ran, not a fallback
+        (out * gout.to(dev)).sum().backward()
+        assert _lib.get_option("last_bwx_kernel") == 2 and _lib.get_option("last_bww_kernel") == 2
+
+        def rel(got, w):
+            w = w.detach().numpy()
+            return float(np.abs(got.detach().cpu().numpy() - w).max() / np.abs(w).max())
+
+        def cos(got, w):
+            a, b = got.detach().cpu().numpy().ravel().astype(np.float64), w.detach().numpy().ravel().astype(np.float64)
+            return float(a @ b / np.sqrt((a @ a) * (b @ b)))
+
+        assert rel(out, want) < 2e-2, rel(out, want)
+        pairs = [(xg.grad, x.grad)] + [(c.weight.grad, W[i].grad) for i, c in enumerate(layer.conv1ds)] + \
+            [(c.bias.grad, Bs[i].grad) for i, c in enumerate(layer.conv1ds)]
+        for got, w in pairs:
+            assert cos(got, w) > 0.999, cos(got, w)
+            if act == "linear":
+                assert rel(got, w) < 4e-2, rel(got, w)
+    finally:
+        _lib.set_option("cin_math", old)
+
+
+def test_model_in_bf16_cin_arithmetic_tracks_the_fp32_modes():
+    """Whole model, config-5 shape (22 sparse fields, D = 32, cin (512,256,256,128)), 6 Adam steps in cin_math 2 and in
+    cin_math 1 from the same initial weights on the same batches: losses within 2e-3 relative, predictions within 5e-3
+    absolute, logloss / AUC of the final predictions within 2e-3 -- the bf16 tolerance of SURVEY 8(d)."""
+    from deepctr.inputs import SparseFeat
+    from deepctr.models import xDeepFM
+    from oracle import xdeepfm_oracle as orc
+    from xdfm_amd import _lib, metrics as M
+    dev = _dev()
+    vocab, D, B = [500] * 22, 32, 512
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)]
+    old = _lib.get_option("cin_math")
+
+    def run(mode):
+        _lib.set_option("cin_math", mode)
+        model = xDeepFM(cols, cols, cin_layer_size=(512, 256, 256, 128), dnn_hidden_units=(256, 256), init_std=0.05, device=dev)
+        model.compile("adam", "binary_crossentropy", metrics=[])
+        model.train()
+        losses = []
+        for s in range(6):
+            X, y = orc.synthetic_batch(B, vocab, 0, seed=40 + s)
+            losses.append(float(model.train_on_batch(T(X).to(dev), T(y).to(dev))[1]))
+        X, y = orc.synthetic_batch(2048, vocab, 0, seed=99)
+        names = list(model.feature_index.keys())
+        return losses, model.predict({n: X[:, i] for i, n in enumerate(names)}, 512), y
+
+    try:
+        l2, p2, y = run(2)
+        l1, p1, _ = run(1)
+    finally:
+        _lib.set_option("cin_math", old)
+    np.testing.assert_allclose(l2, l1, rtol=2e-3)
+    assert np.abs(p2 - p1).max() < 5e-3
+    assert abs(M.log_loss(y, p2) - M.log_loss(y, p1)) < 2e-3 and abs(M.roc_auc_score(y, p2) - M.roc_auc_score(y, p1)) < 2e-3
+
+
 def _near_zero_preactivation_columns(x0, W, Bs, eps):
     """[B, D] mask of the (example, d) columns in which some CIN pre-activation has |z| < eps
     (level loop of deepctr/layers/interaction.py:216-243, split_half=True, relu)."""

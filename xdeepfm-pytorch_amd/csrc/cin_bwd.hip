@@ -778,7 +778,7 @@ int xdfm_cin_level_bwd_x_ex(const float* dOut, const float* xp, const float* x0,
     XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_x: bad shape H=%d (<=256) Hp=%d m=%d",
                  H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_bwx_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_BWX, 1); return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st); }
+    if (x3_bwx_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_BWX, xdfm_opt(OPT_CIN_MATH)); return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st); }
     xdfm_opt_note(OPT_LAST_BWX, 0);
     switch (bwx_hs4(H)) {
         case 1: return launch_bwd_x<1>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
@@ -794,7 +794,7 @@ size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m, long N) {
     if (H <= 0 || Hp <= 0 || m <= 0 || N <= 0) return 0;
     const BwwGeom g = bww_geometry(H, Hp, m, N);
     const size_t f32 = (size_t)g.slab * (size_t)(xdfm_opt(OPT_BWW_SLAB) ? g.nsplit : 1);
-    if (xdfm_opt(OPT_CIN_MATH) == 1) {      // whether the f16x3 kernel runs also depends on pointer alignment
+    if (x3_terms() != 0) {      // whether the f16x3 / bf16 kernel runs also depends on pointer alignment
         const size_t x3 = x3_bww_ws_elems(H, Hp, m, N);
         return x3 > f32 ? x3 : f32;
     }
@@ -806,7 +806,7 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, in
     XDFM_REQUIRE(dOut && xp && x0 && ws && dW, "cin_level_bwd_w: null pointer");
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_w: bad shape H=%d Hp=%d m=%d", H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_bww_usable(dOut, xp, x0, H, N)) { xdfm_opt_note(OPT_LAST_BWW, 1); return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, st); }
+    if (x3_bww_usable(dOut, xp, x0, H, N)) { xdfm_opt_note(OPT_LAST_BWW, xdfm_opt(OPT_CIN_MATH)); return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, st); }
     xdfm_opt_note(OPT_LAST_BWW, 0);
     const int phase = xdfm_opt(OPT_BWW_PHASE);            // fp32 kernels: the whole call counts as phase 2
     if (phase == 1 || phase == 3) return XDFM_OK;

@@ -455,7 +455,7 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_fwd: bad shape H=%d Hp=%d m=%d N=%ld", H, Hp, m, N);
     XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_level_fwd: unsupported activation %d", act);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_fwd_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_FWD, 1); return x3_level_fwd(xp, x0, Wf, bias, H, Hp, m, N, act, out, st); }
+    if (x3_fwd_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_FWD, xdfm_opt(OPT_CIN_MATH)); return x3_level_fwd(xp, x0, Wf, bias, H, Hp, m, N, act, out, st); }
     xdfm_opt_note(OPT_LAST_FWD, 0);
     const int nf = xdfm_opt(OPT_FWD_NF) == 2 ? 2 : 1;
     switch (fwd_mt(H)) {

@@ -15,9 +15,23 @@
 #include <type_traits>
 #include "xdfm_internal.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));      // 16 bytes of MFMA operand (fp16 halves, or bf16 bit patterns)
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> two bf16 (RNE, v_cvt_pk_bf16_f32) carried as the bit patterns of an h2
+__device__ __forceinline__ h2 x3_bf16_pair(float a, float b) {
+    const f2 z = {a, b};
+    return __builtin_bit_cast(h2, __builtin_convertvector(z, bf2));
+}
+// one MFMA term: NT == 3 -> fp16 operands, NT == 1 -> the same 16 bytes read as bf16
+template <int NT>
+__device__ __forceinline__ f32x16 x3_mfma(const h8& a, const h8& b, const f32x16& c) {
+    if constexpr (NT == 3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -46,7 +60,9 @@ X3Geom x3_fwd_geom(int H, int Hp, int m) {
 
 bool x3_fwd_usable(int H, int Hp, int m) {
     (void)Hp;
-    return xdfm_opt(OPT_CIN_MATH) == 1 && (m == 26 || m == 22) && H > 32;
+    const int nt = x3_terms();
+    // bf16: one 1-KB fragment per row tile and step, so a ring stage of < 4 row tiles cannot be dealt to 4 waves
+    return nt != 0 && (m == 26 || m == 22) && H > (nt == 3 ? 32 : 64);
 }
 
 // power of two s with amax*s in [2^(target-1), 2^target); 1 for amax == 0 or denormal
@@ -144,9 +160,10 @@ __device__ __forceinline__ float x3_weight_scale(const float* __restrict__ hdr, 
 //   [mb][g < NS+2][mt < MT][p: 0 = hi, 1 = lo][lane][8 halves]   -- 1 KB per (mt, p) fragment
 // element t of lane (r = lane & 31, hh = lane >> 5) of step g = (blk, s):
 //   row = (mb*MT + mt)*32 + r,  q = 8s + t,  il = q / m,  j = q % m,  i = blk*8 + hh*RH + il
+// bf16 (nt == 1): no scale (sW = 1), one fragment per (g, mt): the bf16 bit patterns of W
 __device__ __forceinline__ void x3_fwd_pack_one(const float* __restrict__ W, int H, int Hp, int m, const X3Geom& G,
-                                                int nparts, float* __restrict__ pack, long idx) {
-    const float sW = x3_weight_scale(pack, nparts);
+                                                int nparts, float* __restrict__ pack, long idx, int nt) {
+    const float sW = nt == 3 ? x3_weight_scale(pack, nparts) : 1.f;
     if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
     const int lane = (int)(idx & 63);
     long rest = idx >> 6;
@@ -165,19 +182,27 @@ __device__ __forceinline__ void x3_fwd_pack_one(const float* __restrict__ W, int
         const int i = blk * 8 + hh * RH + il;
         float v = 0.f;
         if (g < G.NS && row < H && il < RH && i < Hp) v = W[(long)row * ((long)Hp * m) + (long)i * m + j] * sW;
-        const _Float16 a = (_Float16)v;
-        hi[t] = a;
-        lo[t] = (_Float16)(v - (float)a);
+        if (nt == 3) {
+            const _Float16 a = (_Float16)v;
+            hi[t] = a;
+            lo[t] = (_Float16)(v - (float)a);
+        } else {
+            hi[t] = __builtin_bit_cast(_Float16, (__bf16)v);
+        }
     }
-    h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (((long)mb * (G.NS + 2) + g) * G.MT + mt) * 128 + lane;
-    dst[0] = hi;
-    dst[64] = lo;
+    if (nt == 3) {
+        h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (((long)mb * (G.NS + 2) + g) * G.MT + mt) * 128 + lane;
+        dst[0] = hi;
+        dst[64] = lo;
+    } else {
+        reinterpret_cast<h8*>(pack + X3_HDR)[(((long)mb * (G.NS + 2) + g) * G.MT + mt) * 64 + lane] = hi;
+    }
 }
 
 __global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3Geom G, int nparts,
-                                   float* __restrict__ pack) {
+                                   float* __restrict__ pack, int nt) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)G.MB * (G.NS + 2) * G.MT * 64) x3_fwd_pack_one(W, H, Hp, m, G, nparts, pack, idx);
+    if (idx < (long)G.MB * (G.NS + 2) * G.MT * 64) x3_fwd_pack_one(W, H, Hp, m, G, nparts, pack, idx, nt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -185,13 +210,15 @@ __global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, i
 // 32 columns and all MT row tiles.  The packed weight fragments of one step (2*MT KB) are shared by the
 // four waves through a 3-deep LDS ring filled by 16-byte LDS-DMA two steps ahead (one counted
 // s_waitcnt vmcnt + raw s_barrier per step); each wave builds its own B operand (Z hi / lo) in registers.
-template <int MT, int M, int NW, int R = 3>
+// NT = MFMA terms per product: 3 (f16x3: hi / lo fp16 halves, range-fitted) or 1 (bf16 operands, no scales)
+template <int MT, int M, int NW, int R = 3, int NT = 3>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ pack,
     const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MP = M / 2;
-    constexpr int FR = 2 * MT;                  // 1-KB fragments per stage
+    constexpr int FRT = NT == 3 ? 2 : 1;        // 1-KB fragments per row tile (hi, lo | bf16)
+    constexpr int FR = FRT * MT;                // 1-KB fragments per stage
     constexpr int STAGE = FR * 1024;            // bytes
     constexpr int FPW = FR / NW;                // LDS-DMA instructions per wave and stage
     static_assert(FR % NW == 0, "every wave issues the same number of LDS-DMA pieces");
@@ -256,13 +283,15 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
         a0 = fmaxf(a0, fabsf(x0r[j]));
     }
     float ap = 0.f;
-    if (xp == x0) {
+    if (NT != 3) {
+    } else if (xp == x0) {
         ap = a0;
     } else {
         ap = x3_col_absmax(xp + nc, N, hh, Hp);
         ap = fmaxf(ap, __shfl_xor(ap, 32)) * nmask;
     }
-    const float s0 = x3_pow2_scale(a0, 7), sp = x3_pow2_scale(ap, 7);
+    // bf16 operands need no range fitting
+    const float s0 = NT == 3 ? x3_pow2_scale(a0, 7) : 1.f, sp = NT == 3 ? x3_pow2_scale(ap, 7) : 1.f;
 #pragma unroll
     for (int j = 0; j < M; ++j) x0r[j] *= s0;
 
@@ -288,9 +317,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
 #pragma unroll
         for (int t2 = 0; t2 < 4; ++t2) {
             const int q = 8 * s + 2 * t2, il = q / M, j = q - il * M;
-            h2 hi, lo;
-            if (il < 4) x3_split_prod2(xv[il], x0r[j], xv[il], x0r[j + 1], hi, lo);
-            else { hi = h2{0, 0}; lo = h2{0, 0}; }
+            h2 hi = h2{0, 0}, lo = h2{0, 0};
+            if (il < 4) {
+                if constexpr (NT == 3) x3_split_prod2(xv[il], x0r[j], xv[il], x0r[j + 1], hi, lo);
+                else hi = x3_bf16_pair(xv[il] * x0r[j], xv[il] * x0r[j + 1]);
+            }
             bh[2 * t2] = hi.x; bh[2 * t2 + 1] = hi.y;
             bl[2 * t2] = lo.x; bl[2 * t2 + 1] = lo.y;
         }
@@ -338,11 +369,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             const char* st = smem + so[s % R] + lane * 16;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const h8 ah = *reinterpret_cast<const h8*>(st + (2 * mt) * 1024);
-                const h8 al = *reinterpret_cast<const h8*>(st + (2 * mt + 1) * 1024);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[mt], 0, 0, 0);
-                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[mt], 0, 0, 0);
+                const h8 ah = *reinterpret_cast<const h8*>(st + (FRT * mt) * 1024);
+                acc[mt] = x3_mfma<NT>(ah, bh, acc[mt]);
+                if constexpr (NT == 3) {
+                    const h8 al = *reinterpret_cast<const h8*>(st + (2 * mt + 1) * 1024);
+                    acc[mt] = x3_mfma<NT>(ah, bl, acc[mt]);
+                    acc[mt] = x3_mfma<NT>(al, bh, acc[mt]);
+                }
             }
             bh = nh; bl = nl;
             }
@@ -367,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     // The bias values of the workgroup's rows sit in LDS since the prologue: their reads count on lgkmcnt, so nothing
     // makes hipcc put an s_waitcnt vmcnt(0) -- which also waits for the previous STORE -- in front of every store
     // (with per-row global loads of the bias it did: 16 write round trips per row tile).
-    const float sc = pack[1] * (1.f / sp) * (1.f / s0);
+    const float sc = NT == 3 ? pack[1] * (1.f / sp) * (1.f / s0) : 1.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         __builtin_amdgcn_sched_barrier(0);          // one row tile at a time: 16 store addresses live, not 16 * MT
@@ -384,51 +417,60 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
 // ---------------------------------------------------------------------------------------------
 size_t x3_fwd_pack_elems(int H, int Hp, int m) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
-    return (size_t)X3_HDR + (size_t)g.MB * (g.NS + 2) * g.MT * 512;       // 2 KB = 512 floats per (step, row tile)
+    // 2 KB (hi + lo) = 512 floats per (step, row tile); bf16: 1 KB
+    return (size_t)X3_HDR + (size_t)g.MB * (g.NS + 2) * g.MT * (x3_terms() == 3 ? 512 : 256);
 }
 
 int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
     const long total = (long)H * Hp * m;
-    x3_launch_absmax(W, total, pack, st);
+    const int nt = x3_terms();
+    if (nt == 3) x3_launch_absmax(W, total, pack, st);
     const long threads = (long)g.MB * (g.NS + 2) * g.MT * 64;
     hipLaunchKernelGGL(x3_fwd_pack_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, st, W, H, Hp, m, g,
-                       x3_absmax_blocks(total), pack);
-    return xdfm_check_launch("cin_fwd_pack (f16x3)");
+                       x3_absmax_blocks(total), pack, nt);
+    return xdfm_check_launch("cin_fwd_pack (f16x3 / bf16)");
 }
 
 // NW waves (= 32*NW columns) share one weight ring: 8 waves halve the L2 -> LDS traffic of the ring (every
 // workgroup streams the whole packed matrix: 512 x 1.7 MB per launch at config 2 with 4 waves)
-template <int MT, int M>
+template <int MT, int M, int NT>
 static int launch_x3(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, long N,
                      const X3Geom& g, int act, float* out, hipStream_t st) {
-    const size_t lds = (size_t)3 * 2 * MT * 1024;
-    constexpr int NWMAX = (2 * MT) % 8 == 0 ? 8 : 4;
+    constexpr int FR = (NT == 3 ? 2 : 1) * MT;
+    constexpr int NWMAX = FR % 8 == 0 ? 8 : 4;
+    static_assert(FR % 4 == 0, "a ring stage is dealt to 4 or 8 waves");
+    // ring (3 weight stages) + bias of the workgroup's rows + two x_prev buffers
     if constexpr (NWMAX == 8) {
         if (xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64) {
             const dim3 grid(ceil_div(N, 32 * NWMAX), g.MB), block(64 * NWMAX);
-            // ring (weight stages) + bias of the workgroup's rows + two x_prev buffers
-            const size_t ldsx = (size_t)3 * 2 * MT * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
-            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, 3>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
-            return xdfm_check_launch("cin_level_fwd (f16x3)");
+            const size_t ldsx = (size_t)3 * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
+            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, 3, NT>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
+            return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
         }
     }
-    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds + (size_t)2 * 8 * 128 * sizeof(float) + 32 * MT * sizeof(float), st, xp, x0, pack,
+    const size_t lds4 = (size_t)3 * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 128 * sizeof(float);
+    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4, 3, NT>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds4, st, xp, x0, pack,
                        bias, H, Hp, N, g, act, out);
-    return xdfm_check_launch("cin_level_fwd (f16x3)");
+    return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
 }
 
 int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
                  int act, float* out, hipStream_t st) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
+    const int nt = x3_terms();
     act |= ((xdfm_opt(OPT_DBG) >> 6) & 255) << 8;     // timing experiments (results become wrong): see the kernels' `dbg`
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd: packed weights must be 16-byte aligned");
 #define X3_CASE(MTV, MV) \
-    if (g.MT == MTV && m == MV) return launch_x3<MTV, MV>(xp, x0, pack, bias, H, Hp, N, g, act, out, st);
+    if (g.MT == MTV && m == MV && nt == 3) return launch_x3<MTV, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, st);
+#define X1_CASE(MTV, MV) \
+    if (g.MT == MTV && m == MV && nt == 1) return launch_x3<MTV, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, st);
     X3_CASE(2, 26) X3_CASE(4, 26) X3_CASE(8, 26)
     X3_CASE(2, 22) X3_CASE(4, 22) X3_CASE(8, 22)
+    X1_CASE(4, 26) X1_CASE(8, 26) X1_CASE(4, 22) X1_CASE(8, 22)
 #undef X3_CASE
-    return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd (f16x3): no kernel for MT=%d m=%d", g.MT, m);
+#undef X1_CASE
+    return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd (f16x3 / bf16): no kernel for MT=%d m=%d terms=%d", g.MT, m, nt);
 }
 
 // =============================================================================================
@@ -451,14 +493,16 @@ X3BwxGeom x3_bwx_geom(int H, int Hp, int m) {
 
 bool x3_bwx_usable(int H, int Hp, int m) {
     (void)Hp; (void)m;
-    return xdfm_opt(OPT_CIN_MATH) == 1 && H > 16 && H <= 256;
+    const int nt = x3_terms();
+    // bf16: 1 KB per h-block, so a ring stage of < 4 h-blocks (H <= 32) cannot be dealt to 4 waves
+    return nt != 0 && H > (nt == 3 ? 16 : 32) && H <= 256;
 }
 
 // pack: [tile = iblk*m + j][hb < HBT][p][lane][8 halves]; element t of lane (r, hh):
 //   W[h = 16*hb + 8*hh + t][(iblk*32 + r)*m + j] * sW   (0 outside); two dummy stages appended.
 __device__ __forceinline__ void x3_bwx_pack_one(const float* __restrict__ W, int H, int Hp, int m, const X3BwxGeom& G,
-                                                int nparts, float* __restrict__ pack, long idx) {
-    const float sW = x3_weight_scale(pack, nparts);
+                                                int nparts, float* __restrict__ pack, long idx, int nt) {
+    const float sW = nt == 3 ? x3_weight_scale(pack, nparts) : 1.f;
     if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
     const int lane = (int)(idx & 63);
     long rest = idx >> 6;
@@ -474,19 +518,27 @@ __device__ __forceinline__ void x3_bwx_pack_one(const float* __restrict__ W, int
         const int h = 16 * hb + 8 * hh + t;
         float v = 0.f;
         if (tile < G.NT && h < H && i < Hp) v = W[(long)h * ((long)Hp * m) + (long)i * m + j] * sW;
-        const _Float16 a = (_Float16)v;
-        hi[t] = a;
-        lo[t] = (_Float16)(v - (float)a);
+        if (nt == 3) {
+            const _Float16 a = (_Float16)v;
+            hi[t] = a;
+            lo[t] = (_Float16)(v - (float)a);
+        } else {
+            hi[t] = __builtin_bit_cast(_Float16, (__bf16)v);
+        }
     }
-    h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (tile * G.HBT + hb) * 128 + lane;
-    dst[0] = hi;
-    dst[64] = lo;
+    if (nt == 3) {
+        h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (tile * G.HBT + hb) * 128 + lane;
+        dst[0] = hi;
+        dst[64] = lo;
+    } else {
+        reinterpret_cast<h8*>(pack + X3_HDR)[(tile * G.HBT + hb) * 64 + lane] = hi;
+    }
 }
 
 __global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3BwxGeom G, long total,
-                                   int nparts, float* __restrict__ pack) {
+                                   int nparts, float* __restrict__ pack, int nt) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < total) x3_bwx_pack_one(W, H, Hp, m, G, nparts, pack, idx);
+    if (idx < total) x3_bwx_pack_one(W, H, Hp, m, G, nparts, pack, idx, nt);
 }
 
 // ---- all levels, both directions, in two launches (the packs depend on the weights only) ----------------------
@@ -497,6 +549,7 @@ struct X3PackJobs {
     float* bwd[X3_MAXJOBS];
     int H[X3_MAXJOBS], Hp[X3_MAXJOBS], m[X3_MAXJOBS], nparts[X3_MAXJOBS];
     long nW[X3_MAXJOBS], fthreads[X3_MAXJOBS], bthreads[X3_MAXJOBS];
+    int nt;
     X3Geom fg[X3_MAXJOBS];
     X3BwxGeom bg[X3_MAXJOBS];
 };
@@ -536,24 +589,25 @@ __global__ __launch_bounds__(256) void x3_pack_multi_kernel(const X3PackJobs J) 
     if (dir == 0) {
         if (!J.fwd[l]) return;
         for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.fthreads[l]; idx += stride)
-            x3_fwd_pack_one(J.W[l], J.H[l], J.Hp[l], J.m[l], J.fg[l], J.nparts[l], J.fwd[l], idx);
+            x3_fwd_pack_one(J.W[l], J.H[l], J.Hp[l], J.m[l], J.fg[l], J.nparts[l], J.fwd[l], idx, J.nt);
     } else {
         if (!J.bwd[l]) return;
         for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.bthreads[l]; idx += stride)
-            x3_bwx_pack_one(J.W[l], J.H[l], J.Hp[l], J.m[l], J.bg[l], J.nparts[l], J.bwd[l], idx);
+            x3_bwx_pack_one(J.W[l], J.H[l], J.Hp[l], J.m[l], J.bg[l], J.nparts[l], J.bwd[l], idx, J.nt);
     }
 }
 
-template <int HBT, int NW>
+template <int HBT, int NW, int NT = 3>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
     const float* __restrict__ dOut, const float* xp, const float* x0, const float* __restrict__ pack,
     int H, int Hp, int m, long N, int IB, float* dxp, float* dx0, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HBS = HBT > 8 ? 8 : HBT;      // h-blocks per stage
     constexpr int SPT = HBT / HBS;              // stages per tile
-    constexpr int STAGE = HBS * 2048;
-    constexpr int FPW = HBS * 2 / NW;
-    static_assert((HBS * 2) % NW == 0, "every wave issues the same number of LDS-DMA pieces");
+    constexpr int FRT = NT == 3 ? 2 : 1;        // 1-KB fragments per h-block (hi, lo | bf16)
+    constexpr int STAGE = HBS * FRT * 1024;
+    constexpr int FPW = HBS * FRT / NW;
+    static_assert((HBS * FRT) % NW == 0, "every wave issues the same number of LDS-DMA pieces");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, hh = lane >> 5;
@@ -597,10 +651,12 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
 
     // B operand: dOut[h][n] for all h of this launch, column-scaled and split, in registers
     float dmax = 0.f;
-    dmax = x3_col_absmax(dOut + nc, N, hh, H);
-    dmax = fmaxf(dmax, __shfl_xor(dmax, 32)) * nmask;
-    const float sD = x3_pow2_scale(dmax, 15);
-    h8 bh[HBT], bl[HBT];
+    if constexpr (NT == 3) {
+        dmax = x3_col_absmax(dOut + nc, N, hh, H);
+        dmax = fmaxf(dmax, __shfl_xor(dmax, 32)) * nmask;
+    }
+    const float sD = NT == 3 ? x3_pow2_scale(dmax, 15) : 1.f;     // bf16 operands need no range fitting
+    h8 bh[HBT], bl[NT == 3 ? HBT : 1];
 #pragma unroll
     for (int hb = 0; hb < HBT; ++hb) {
 #pragma unroll
@@ -609,12 +665,16 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
             const float v0 = dOut[(long)(h < H ? h : H - 1) * N + nc] * ((h < H) ? sD * nmask : 0.f);
             const float v1 = dOut[(long)(h + 1 < H ? h + 1 : H - 1) * N + nc] * ((h + 1 < H) ? sD * nmask : 0.f);
             h2 hi, lo;
-            x3_split2(v0, v1, hi, lo);
+            if constexpr (NT == 3) {
+                x3_split2(v0, v1, hi, lo);
+                bl[hb][2 * t2] = lo.x; bl[hb][2 * t2 + 1] = lo.y;
+            } else {
+                hi = x3_bf16_pair(v0, v1);
+            }
             bh[hb][2 * t2] = hi.x; bh[hb][2 * t2 + 1] = hi.y;
-            bl[hb][2 * t2] = lo.x; bl[hb][2 * t2 + 1] = lo.y;
         }
     }
-    const float inv = (1.f / sD) * pack[1];      // removes both scales from dZ
+    const float inv = NT == 3 ? (1.f / sD) * pack[1] : 1.f;      // removes both scales from dZ
 
     int so0 = 0, so1 = STAGE, so2 = 2 * STAGE;   // ring slot of the current stage, +1, +2
     const char* wcur = wsrc;
@@ -646,11 +706,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
 #pragma unroll
                 for (int hbl = 0; hbl < HBS; ++hbl) {
                     const int hb = st * HBS + hbl;
-                    const h8 ah = *reinterpret_cast<const h8*>(sp + (2 * hbl) * 1024);
-                    const h8 al = *reinterpret_cast<const h8*>(sp + (2 * hbl + 1) * 1024);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[hb], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[hb], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[hb], acc, 0, 0, 0);
+                    const h8 ah = *reinterpret_cast<const h8*>(sp + (FRT * hbl) * 1024);
+                    acc = x3_mfma<NT>(ah, bh[hb], acc);
+                    if constexpr (NT == 3) {
+                        const h8 al = *reinterpret_cast<const h8*>(sp + (2 * hbl + 1) * 1024);
+                        acc = x3_mfma<NT>(ah, bl[hb], acc);
+                        acc = x3_mfma<NT>(al, bh[hb], acc);
+                    }
 #pragma unroll
                     for (int r = hb * RPH; r < (hb + 1) * RPH; ++r) {
                         dxa[r] = fmaf(pacc[r], px0, dxa[r]);
@@ -739,45 +801,56 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
 
 size_t x3_bwx_pack_elems(int H, int Hp, int m) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
-    return (size_t)X3_HDR + ((size_t)g.NT * g.HBT + 2 * g.HBS) * 512;
+    return (size_t)X3_HDR + ((size_t)g.NT * g.HBT + 2 * g.HBS) * (x3_terms() == 3 ? 512 : 256);
 }
 
 int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
     const long nW = (long)H * Hp * m;
-    x3_launch_absmax(W, nW, pack, st);
+    const int nt = x3_terms();
+    if (nt == 3) x3_launch_absmax(W, nW, pack, st);
     const long total = ((long)g.NT * g.HBT + 2 * g.HBS) * 64;
     hipLaunchKernelGGL(x3_bwx_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, W, H, Hp, m, g, total,
-                       x3_absmax_blocks(nW), pack);
+                       x3_absmax_blocks(nW), pack, nt);
     return xdfm_check_launch("cin_bwd_pack (f16x3)");
 }
 
-template <int HBT>
+template <int HBT, int NT>
 static int launch_bwx3(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m,
                        long N, const X3BwxGeom& g, float* dxp, float* dx0, int flags, hipStream_t st) {
     constexpr int HBS = HBT > 8 ? 8 : HBT;
-    constexpr int NWMAX = (HBS * 2) % 8 == 0 ? 8 : 4;
-    const size_t lds8 = (size_t)3 * HBS * 2048 + (size_t)2 * NWMAX * m * 32 * sizeof(float);
-    const size_t lds4 = (size_t)3 * HBS * 2048 + (size_t)8 * m * 32 * sizeof(float);
+    constexpr int FR = HBS * (NT == 3 ? 2 : 1);
+    constexpr int NWMAX = FR % 8 == 0 ? 8 : 4;
+    static_assert(FR % 4 == 0, "a ring stage is dealt to 4 or 8 waves");
+    const size_t lds8 = (size_t)3 * FR * 1024 + (size_t)2 * NWMAX * m * 32 * sizeof(float);
+    const size_t lds4 = (size_t)3 * FR * 1024 + (size_t)8 * m * 32 * sizeof(float);
     if (lds4 > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds4);
     if (NWMAX == 8 && xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64 && lds8 <= 160 * 1024)
-        hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, NWMAX>), dim3(ceil_div(N, 32 * NWMAX)), dim3(64 * NWMAX), lds8, st, dOut, xp,
+        hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, NWMAX, NT>), dim3(ceil_div(N, 32 * NWMAX)), dim3(64 * NWMAX), lds8, st, dOut, xp,
                            x0, pack, H, Hp, m, N, g.IB, dxp, dx0, flags);
     else
-        hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, 4>), dim3(ceil_div(N, 128)), dim3(256), lds4, st, dOut, xp, x0, pack, H, Hp,
+        hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, 4, NT>), dim3(ceil_div(N, 128)), dim3(256), lds4, st, dOut, xp, x0, pack, H, Hp,
                            m, N, g.IB, dxp, dx0, flags);
-    return xdfm_check_launch("cin_level_bwd_x (f16x3)");
+    return xdfm_check_launch("cin_level_bwd_x (f16x3 / bf16)");
 }
 
 int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
                    float* dxp, float* dx0, int flags, hipStream_t st) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: packed weights must be 16-byte aligned");
+    if (x3_terms() == 1) {
+        switch (g.HBT) {
+            case 4: return launch_bwx3<4, 1>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+            case 8: return launch_bwx3<8, 1>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+            case 16: return launch_bwx3<16, 1>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+            default: return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x (bf16): no kernel for H=%d", H);
+        }
+    }
     switch (g.HBT) {
-        case 2: return launch_bwx3<2>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
-        case 4: return launch_bwx3<4>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
-        case 8: return launch_bwx3<8>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
-        default: return launch_bwx3<16>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+        case 2: return launch_bwx3<2, 3>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+        case 4: return launch_bwx3<4, 3>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+        case 8: return launch_bwx3<8, 3>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
+        default: return launch_bwx3<16, 3>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
     }
 }
 
@@ -804,7 +877,8 @@ int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st) {
             if (J.nparts[l] > maxparts) maxparts = J.nparts[l];
         }
     }
-    hipLaunchKernelGGL(x3_absmax_multi_kernel, dim3(maxparts, L), dim3(1024), 0, st, J);
+    J.nt = x3_terms();
+    if (J.nt == 3) hipLaunchKernelGGL(x3_absmax_multi_kernel, dim3(maxparts, L), dim3(1024), 0, st, J);
     int gx = ceil_div(maxthreads, 256);
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(x3_pack_multi_kernel, dim3(gx, 2 * L), dim3(256), 0, st, J);

@@ -10,10 +10,18 @@
 //   pass 4  x3_bww_unpack_kernel  ordered sum of the slabs, scales removed, [h][i*m+j] layout
 #include "xdfm_internal.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));      // 16 bytes of MFMA operand (fp16 halves, or bf16 bit patterns)
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+
+template <int NT>
+__device__ __forceinline__ f32x16 x3w_mfma(const h8& a, const h8& b, const f32x16& c) {
+    if constexpr (NT == 3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
 
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
@@ -26,7 +34,7 @@ __device__ __forceinline__ float x3w_pow2_scale(float amax, int target) {
 }
 
 bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, long N) {
-    return xdfm_opt(OPT_CIN_MATH) == 1 && bww_mt(H) == 4 && N % 4 == 0 && N >= 32 &&
+    return x3_terms() != 0 && bww_mt(H) == 4 && N % 4 == 0 && N >= 32 &&
            ((((size_t)dOut) | ((size_t)xp) | ((size_t)x0)) & 15) == 0;
 }
 
@@ -92,13 +100,22 @@ __global__ __launch_bounds__(256) void x3_rowmax_kernel(const float* __restrict_
 // then reduces its own row's nbx partials (uniform loads), and the blockIdx.x == 0 column of blocks also writes the
 // header -- its row's dOut scale, plus (thread t of block row r) entry r*256 + t of the x_prev / x0 scales -- for the
 // MFMA kernel and the unpack pass (no launch of its own for that).
+// nt == 1 (bf16): no scales -- the header is all ones (written here by the blockIdx.x == 0 column) and the hi half of
+// a block holds the bf16 bit patterns of dOut; the lo half is not used (the planes keep the fp16 layout: same kernel,
+// same LDS image; half of the staged bytes are idle in this mode).
 __global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restrict__ dOut, int H, long N, long NP,
                                                            float* __restrict__ hdr, char* __restrict__ planes,
                                                            const float* __restrict__ parts, int nbx, int Hp, int m,
-                                                           int Hpad, int IPAD) {
+                                                           int Hpad, int IPAD, int nt) {
     const int row = blockIdx.y;
     float s_row = 1.f;
-    if (parts) {
+    if (nt == 1) {
+        if (blockIdx.x == 0) {
+            if (threadIdx.x == 0) hdr[row] = 1.f;
+            const int e = row * 256 + threadIdx.x;
+            if (e < IPAD + m) hdr[Hpad + e] = 1.f;
+        }
+    } else if (parts) {
         if (row < H) {
             float mx = 0.f;
             for (int k = 0; k < nbx; ++k) mx = fmaxf(mx, parts[(long)row * nbx + k]);
@@ -138,13 +155,18 @@ __global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restr
     h8 hi, lo;
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const _Float16 a = (_Float16)v[t];
-        hi[t] = a;
-        lo[t] = (_Float16)(v[t] - (float)a);
+        if (nt == 3) {
+            const _Float16 a = (_Float16)v[t];
+            hi[t] = a;
+            lo[t] = (_Float16)(v[t] - (float)a);
+        } else {
+            hi[t] = __builtin_bit_cast(_Float16, (__bf16)v[t]);
+            lo[t] = (_Float16)0.f;
+        }
     }
     char* blk = planes + ((long)row * NP + (n & ~31L)) * 4 + (n & 31) * 2;     // 4 bytes per column and row
     *reinterpret_cast<h8*>(blk) = hi;
-    *reinterpret_cast<h8*>(blk + 64) = lo;
+    if (nt == 3) *reinterpret_cast<h8*>(blk + 64) = lo;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,7 +192,7 @@ __device__ __forceinline__ void x3w_split_prod2(float a0, float b0, float a1, fl
 // wave tile as in cin_bwd_w_dma4_kernel: 32*MT rows of h x (32 i's of block iblk) x JT = 2 values of j
 // NW waves per workgroup share the staged dOut chunk: with 8 waves the planes are streamed by half as many
 // workgroups and half as many n-splits (slabs) are needed to fill the chip with one resident round
-template <int MT, int NW>
+template <int MT, int NW, int NT = 3>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
     const char* __restrict__ planes, long PB, const float* __restrict__ xp, const float* __restrict__ x0,
     const float* __restrict__ hdr, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
@@ -268,9 +290,14 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
                 const float zv[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
 #pragma unroll
                 for (int t2 = 0; t2 < 4; ++t2) {
-                    h2 hi, lo;
+                    h2 hi, lo = h2{0, 0};
                     const f2 xs = (f2){xv[2 * t2], xv[2 * t2 + 1]} * (f2){fz[jt], fz[jt]};     // row scales: exact
-                    x3w_split_prod2(xs.x, zv[2 * t2], xs.y, zv[2 * t2 + 1], hi, lo);
+                    if constexpr (NT == 3) {
+                        x3w_split_prod2(xs.x, zv[2 * t2], xs.y, zv[2 * t2 + 1], hi, lo);
+                    } else {
+                        const f2 z = xs * (f2){zv[2 * t2], zv[2 * t2 + 1]};
+                        hi = __builtin_bit_cast(h2, __builtin_convertvector(z, bf2));
+                    }
                     bh[jt][2 * t2] = hi.x; bh[jt][2 * t2 + 1] = hi.y;
                     bl[jt][2 * t2] = lo.x; bl[jt][2 * t2 + 1] = lo.y;
                 }
@@ -284,12 +311,17 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
             for (int mt = 0; mt < MT; ++mt) {
                 const int qa = nb * 2 + hh;
                 const h8 ah = *reinterpret_cast<const h8*>(dS + ((mt * 32 + r) * 8 + (qa ^ sr)) * 16);
-                const h8 al = *reinterpret_cast<const h8*>(dS + ((mt * 32 + r) * 8 + ((qa + 4) ^ sr)) * 16);
+                if constexpr (NT == 3) {
+                    const h8 al = *reinterpret_cast<const h8*>(dS + ((mt * 32 + r) * 8 + ((qa + 4) ^ sr)) * 16);
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[jt], acc[mt][jt], 0, 0, 0);
-                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[jt], acc[mt][jt], 0, 0, 0);
-                    acc[mt][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[jt], acc[mt][jt], 0, 0, 0);
+                    for (int jt = 0; jt < JT; ++jt) {
+                        acc[mt][jt] = x3w_mfma<3>(ah, bh[jt], acc[mt][jt]);
+                        acc[mt][jt] = x3w_mfma<3>(ah, bl[jt], acc[mt][jt]);
+                        acc[mt][jt] = x3w_mfma<3>(al, bh[jt], acc[mt][jt]);
+                    }
+                } else {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) acc[mt][jt] = x3w_mfma<1>(ah, bh[jt], acc[mt][jt]);
                 }
             }
         }
@@ -389,8 +421,10 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     // the same arguments, are the whole call
     const int phase = xdfm_opt(OPT_BWW_PHASE);
     int rc = XDFM_OK;
+    const int nt = x3_terms();
     if (phase == 0 || phase == 1) {
-    if (w.nbx == 1) {                   // one block covers a row: the maxima pass writes the scales itself
+    if (nt == 1) {                      // bf16: no row scales, no maxima pass
+    } else if (w.nbx == 1) {            // one block covers a row: the maxima pass writes the scales itself
         hipLaunchKernelGGL(x3_rowmax_kernel, dim3(1, g.Hpad + g.IPAD + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, N, parts,
                            hdr, g.Hpad, g.IPAD);
     } else {
@@ -401,18 +435,18 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     // block rows x 256 threads cover the IPAD + m further header entries with room to spare)
     XDFM_REQUIRE((long)g.Hpad * 256 >= g.IPAD + m, "cin_level_bwd_w: header larger than the split pass's grid");
     hipLaunchKernelGGL(x3_split_dout_kernel, dim3(ceil_div(w.NP, 2048), g.Hpad), dim3(256), 0, st, dOut, H, N, w.NP, hdr,
-                       planes, w.nbx == 1 ? (const float*)nullptr : (const float*)parts, w.nbx, Hp, m, g.Hpad, g.IPAD);
+                       planes, w.nbx == 1 ? (const float*)nullptr : (const float*)parts, w.nbx, Hp, m, g.Hpad, g.IPAD, nt);
     rc = xdfm_check_launch("cin_level_bwd_w split");
     if (rc) return rc;
     }
     if (phase == 0 || phase == 2) {
     const size_t lds = (size_t)2 * (32 * 4 + NW * (32 + 8)) * 128;
-    if (NW == 8)
-        hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, 8>), dim3(g.gx, g.nsplit), dim3(512), lds, st, planes, w.NP * 4, xp, x0,
-                           hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab);
-    else
-        hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, 4>), dim3(g.gx, g.nsplit), dim3(256), lds, st, planes, w.NP * 4, xp, x0,
-                           hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab);
+#define BWW_LAUNCH(NWV, NTV) \
+    hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, NWV, NTV>), dim3(g.gx, g.nsplit), dim3(64 * NWV), lds, st, planes, w.NP * 4, xp, \
+                       x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab)
+    if (NW == 8) { if (nt == 3) BWW_LAUNCH(8, 3); else BWW_LAUNCH(8, 1); }
+    else { if (nt == 3) BWW_LAUNCH(4, 3); else BWW_LAUNCH(4, 1); }
+#undef BWW_LAUNCH
     rc = xdfm_check_launch("cin_level_bwd_w (f16x3)");
     if (rc) return rc;
     }

@@ -71,7 +71,10 @@ static inline int bwx_hs4(int H) {      // float4 groups along the contraction (
 // holds element [row = (r&3) + 8*(r>>2) + 4*s][col = c].
 __device__ __forceinline__ int frag_row(int r, int s) { return (r & 3) + 8 * (r >> 2) + 4 * s; }
 
-// ---- f16x3 path (cin_x3*.hip) ------------------------------------------------------------------
+// ---- f16x3 / bf16 path (cin_x3*.hip) -------------------------------------------------------------
+// MFMA terms per fp32 product of the selected arithmetic: 3 = f16x3 (hi*hi + hi*lo + lo*hi on fp16 halves, cin_math 1),
+// 1 = bf16 operands (cin_math 2: one v_mfma_f32_32x32x16_bf16, no range fitting: bf16 has fp32's exponent), 0 = neither
+static inline int x3_terms() { const int m = xdfm_opt(OPT_CIN_MATH); return m == 1 ? 3 : (m == 2 ? 1 : 0); }
 #define X3_HDR 128        // floats in front of a packed weight stream: [0] scale, [1] 1/scale, [64..127] partial maxima of |W|
 struct X3Geom {
     int MT, MB;           // row tiles (of 32) per wave, row groups (blockIdx.y)

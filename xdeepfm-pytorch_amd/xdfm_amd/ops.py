@@ -413,7 +413,7 @@ class CINStack(torch.autograd.Function):
                 dW = torch.empty((H, Hp * m), dtype=torch.float32, device=dev)
                 call = lambda: lib.xdfm_cin_level_bwd_w(_ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW),
                                                         _stream())
-                if PROFILE is not None and _lib.get_option("cin_math") == 1:
+                if PROFILE is not None and _lib.get_option("cin_math") in (1, 2):
                     # per-kernel timing: run the call's three phases separately, events around the MFMA kernel only
                     # (a shape without an f16x3 dW kernel ignores the knob: its whole call then runs once, in phase 2)
                     try:
