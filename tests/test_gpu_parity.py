@@ -33,6 +33,19 @@ def gclose(got, want, msg=""):
     close(got, want, rtol=2e-4, atol=2e-5 * float(np.abs(want).max()) + 1e-9, msg=msg)
 
 
+def _f16x3_kernels_for(m, ls, B, D):
+    """Which arithmetic each CIN kernel of a (m, layer sizes) stack must have run in cin_math 1: the f16x3 forward exists
+    for m in {22, 26} and H > 32, dX for 16 < H <= 256 (per call), dW for H > 64 with 16-byte rows (N % 4 == 0);
+    everything else falls back to the fp32-MFMA kernels -- by design, and the tests say which (no test
+    asserted which kernel ran).  Returns the expected probe values of the LAST level for (fwd, bwx of level 0, bww of level 0)."""
+    H_last, H0 = ls[-1], ls[0]
+    N = B * D
+    fwd = 1 if (m in (22, 26) and H_last > 32) else 0
+    bwx = 1 if 16 < min(H0, 256) <= 256 and H0 > 16 else 0
+    bww = 1 if (H0 > 64 and N % 4 == 0 and N >= 32) else 0
+    return fwd, bwx, bww
+
+
 @pytest.fixture(params=[0, 1], ids=["f32mfma", "f16x3"])
 def cin_math(request):
     """Both arithmetic modes of the CIN contraction: v_mfma_f32_32x32x2_f32 on fp32 operands, and the
@@ -102,6 +115,13 @@ def test_cin_vs_oracle_random(B, m, D, ls, cin_math):
     out = layer(xg)
     close(out, want.detach().numpy(), msg="out")
     (out * gout.to(dev)).sum().backward()
+    from xdfm_amd import _lib
+    if cin_math == 1:              # which kernels ran: the last forward launch is the last level, the last backward launches level 0
+        fwd, bwx, bww = _f16x3_kernels_for(m, ls, B, D)
+        assert (_lib.get_option("last_fwd_kernel"), _lib.get_option("last_bwx_kernel"), _lib.get_option("last_bww_kernel")) == \
+            (fwd, bwx, bww), "unexpected kernel arithmetic for m=%d layers=%s" % (m, ls)
+    else:
+        assert _lib.get_option("last_fwd_kernel") == _lib.get_option("last_bwx_kernel") == _lib.get_option("last_bww_kernel") == 0
     # A ReLU whose pre-activation is within rounding of zero can switch on one side only; its whole
     # (example, d) column of dx then differs legitimately.  Such columns are excluded (and must be rare).
     risky = _near_zero_preactivation_columns(x.detach(), [w.detach() for w in W], [b.detach() for b in Bs], 4e-6)
@@ -293,6 +313,89 @@ def test_cin_f16x3_is_as_accurate_as_fp32_mfma(B, m, D, ls, spread):
     assert err[1]["dx"] <= 2.0 * err[0]["dx"] + 2e-7, err
     for a, b in zip(err[1]["dw"], err[0]["dw"]):
         assert a <= 2.0 * b + 2e-7 and a < 5e-6, err
+
+
+@pytest.mark.parametrize("case", ["fields", "weight_row", "dout_rows"])
+def test_cin_f16x3_range_fitting_corners(case):
+    """The fp16 halves of the f16x3 arithmetic are range-fitted per scale GROUP (forward / dX: one scale per column n
+    for x0[:, n], x_prev[:, n], dOut[:, n], one per level for W; dW: one per row).  VERDICT r1 asked for wide dynamic
+    range INSIDE one group, against the fp64 CIN, measured on the small entries:
+      fields      the 26 fields of every x0 column span 1e-6 .. 1 (field j scaled by 10^(-6 j / 25));
+      weight_row  one weight row of every level is 1e6 x the others (one scale per level);
+      dout_rows   the upstream gradient spans 8 decades over the examples, i.e. inside every row of dOut (dW scales rows).
+    Bound asserted: 1e-5 of the magnitude of the entry's own group (example row / field / weight row) for outputs,
+    dx and dW -- elements further than 2^18 below their group's maximum keep an ABSOLUTE error of 2^-40 of that
+    maximum (include/xdfm.h), which these cases show is enough.  The kernels that ran are asserted (no silent fallback)."""
+    from deepctr.layers import CIN
+    from xdfm_amd import _lib
+    dev = _dev()
+    B, m, D, ls = 384, 26, 16, (256, 128, 128)
+    torch.manual_seed(7)
+    layer = CIN(m, ls, "relu", True, 0.0, 1024, device="cpu").to(dev)
+    x = torch.randn(B, m, D, device=dev) * 0.5
+    fscale = torch.ones(m, device=dev)
+    if case == "fields":
+        fscale = torch.pow(10.0, -6.0 * torch.arange(m, device=dev) / (m - 1))
+        x = x * fscale[None, :, None]
+    big_rows = []
+    if case == "weight_row":
+        with torch.no_grad():
+            for c in layer.conv1ds:             # the LAST row: a direct-connect map, so the next level's inputs stay ordinary
+                c.weight[-1] *= 1e6
+                c.bias[-1] *= 1e6
+            big_rows = [-1]
+    gscale = torch.ones(B, 1, device=dev)
+    if case == "dout_rows":
+        gscale = torch.pow(10.0, torch.rand(B, 1, device=dev) * 8 - 8)
+    W64 = [c.weight.detach().double().requires_grad_(True) for c in layer.conv1ds]
+    B64 = [c.bias.detach().double().requires_grad_(True) for c in layer.conv1ds]
+    with torch.no_grad():                      # drop examples with a pre-activation within rounding of the ReLU kink
+        hid, safe = x.double(), torch.ones(B, dtype=torch.bool, device=dev)
+        for i, (w, b) in enumerate(zip(W64, B64)):
+            z = torch.nn.functional.conv1d(torch.einsum("bhd,bmd->bhmd", hid, x.double()).reshape(B, -1, D), w, b)
+            ref = z.abs().amax(dim=1, keepdim=True)
+            if big_rows:                        # the kink test is per row group: the huge row must not hide the others
+                small = torch.ones(z.shape[1], dtype=torch.bool, device=dev)
+                small[big_rows] = False
+                ref = z[:, small].abs().amax(dim=1, keepdim=True)
+                safe &= ~(z[:, small].abs() < 1e-5 * ref).flatten(1).any(dim=1)
+            else:
+                safe &= ~(z.abs() < 1e-5 * ref).flatten(1).any(dim=1)
+            hid = torch.relu(z)[:, : w.shape[0] // 2]
+    assert float(safe.float().mean()) > 0.2
+    x, gscale = x[safe].contiguous(), gscale[safe]
+    x64 = x.double().requires_grad_(True)
+    want = _cin_fp64(x64, W64, B64)
+    gout = torch.randn(want.shape, device=dev) * gscale
+    (want * gout.double()).sum().backward()
+    old = _lib.get_option("cin_math")
+    try:
+        _lib.set_option("cin_math", 1)
+        for c in layer.conv1ds:
+            c.weight.grad = c.bias.grad = None
+        xg = x.clone().requires_grad_(True)
+        out = layer(xg)
+        assert _lib.get_option("last_fwd_kernel") == 1
+        (out * gout).sum().backward()
+        assert _lib.get_option("last_bwx_kernel") == 1 and _lib.get_option("last_bww_kernel") == 1
+    finally:
+        _lib.set_option("cin_math", old)
+    # outputs: per feature map relative to that feature map's magnitude over the batch (the maps of small weight rows
+    # are 1e6 x smaller than the huge row's) and per example
+    e = (out.detach().double() - want.detach()).abs()
+    per_map = (e / want.detach().abs().amax(dim=0, keepdim=True).clamp_min(1e-300)).max().item()
+    per_ex = (e / want.detach().abs().amax(dim=1, keepdim=True).clamp_min(1e-300)).max().item()
+    # dx: per (example, field) relative to that field's gradient magnitude in the example -- small fields on their own
+    gx, wx = xg.grad.double(), x64.grad
+    dx = ((gx - wx).abs().amax(dim=2) / wx.abs().amax(dim=2).clamp_min(1e-300)).max().item()
+    # dW: per (level, weight row h, field j) group relative to the group's largest entry
+    dw = 0.0
+    for c, w in zip(layer.conv1ds, W64):
+        H = w.shape[0]
+        g, ww = c.weight.grad.double().reshape(H, -1, m), w.grad.reshape(H, -1, m)
+        dw = max(dw, ((g - ww).abs().amax(dim=1) / ww.abs().amax(dim=1).clamp_min(1e-300)).max().item())
+    assert per_ex < 1e-5 and dx < 1e-5 and dw < 1e-5, (case, per_map, per_ex, dx, dw)
+    assert per_map < (1e-5 if case != "weight_row" else 4e-5), (case, per_map)
 
 
 def test_cin_rejects_bad_input_like_reference():
