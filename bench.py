@@ -177,10 +177,11 @@ PMC_KERNEL = {"cin_level_bwd_x": "cin_bwd_x3_kernel", "cin_level_bwd_w": "cin_bw
 
 def pmc_traffic(bracket, workload, math_mode):
     """HBM-side bytes per launch of the roofline kernel.  Performance counters cannot be read from inside this process,
-    so the figure comes from the committed rocprofv3 --pmc passes over tools/pmc_cin.py (same kernels, same shapes as
-    the default workload: FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950) -- profiles/r01_pmc_cin_traffic.{md,json}.  null for any other workload or arithmetic."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_cin_traffic.json")
+    so the figure comes from the committed rocprofv3 --pmc passes over THIS script (tools/profile_round.sh: bench.py with
+    eager launches, XDFM_HIP_GRAPH=0 -- counter collection over the graph-replayed step hung in round 1; FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) --
+    profiles/r02_pmc_bench_traffic.json, profiles/r02_pmc_cin.md.  null for any other workload or arithmetic."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_bench_traffic.json")
     if workload != "criteo_c2" or math_mode != 1 or bracket not in PMC_KERNEL or not os.path.exists(path):
         return {}
     rows = [v for k, v in json.load(open(path)).items() if k.startswith(PMC_KERNEL[bracket])]
@@ -189,7 +190,7 @@ def pmc_traffic(bracket, workload, math_mode):
         return {}
     total = sum(v["total_bytes"] * v["launches"] for v in rows) / n
     return dict(traffic=round(total), traffic_unit="bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, mean over the levels)",
-                traffic_source="profiles/r01_pmc_cin_traffic.md")
+                traffic_source="profiles/r02_pmc_cin.md (rocprofv3 --pmc over bench.py, eager launches)")
 
 
 def main():

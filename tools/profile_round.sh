@@ -1,0 +1,27 @@
+#!/bin/bash
+# Profiles of one round, on the GPU box, from the repo root:  bash tools/profile_round.sh r02
+# kernel-trace statistics of bench.py for the headline workload (criteo-card), the mid vocabulary, config 3 and config 5,
+# then counter passes (separate runs, --kernel-trace only next to --pmc).  The bench.py counter passes run with
+# XDFM_HIP_GRAPH=0 (eager launches): round 1's counter pass over the graph-replayed step hung.
+set -u
+R=${1:-r02}
+OUT=gpurun_out/$R
+mkdir -p $OUT
+export TMPDIR=/tmp
+B="--steps 30 --warmup 5 --no-cpu-baseline --no-alt --no-extras"
+run_kt() {  # name, bench args
+  local name=$1; shift
+  timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/kt_$name -o kt -f csv -- python3 bench.py $B "$@" > $OUT/kt_$name.json 2> $OUT/kt_$name.err || { echo "kt $name failed"; return 1; }
+  python3 tools/profile_summary.py $OUT/kt_$name 39 $OUT/${R}_kernel_stats_$name.md "bench.py $B $* under rocprofv3 --kernel-trace --stats (39 profiled steps: 4 pre-capture, 5 warm-up + 30 timed replays... counted as launched); bench line of this run: $(tail -1 $OUT/kt_$name.json | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "ms/step")')"
+}
+run_kt card && run_kt mid --vocab-preset mid && run_kt c3 --workload criteo_c3_attn && run_kt c5 --workload avazu_c5 || exit 1
+echo "== MFMA pipe counters of the CIN kernels"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_m -o pmc -f csv -- python3 tools/pmc_cin.py > $OUT/pmc_m.log 2>&1 && python3 tools/pmc_summary.py $OUT/pmc_m cin_ > $OUT/${R}_pmc_cin_mfma.txt || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_s -o pmc -f csv -- python3 tools/pmc_cin.py > $OUT/pmc_s.log 2>&1 && python3 tools/pmc_summary.py $OUT/pmc_s cin_ > $OUT/${R}_pmc_cin_waves.txt || exit 1
+echo "== HBM traffic counters over bench.py itself (eager launches)"
+export XDFM_HIP_GRAPH=0
+PB="--steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-extras --vocab-preset mid"
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_f -o pmc -f csv -- python3 bench.py $PB > $OUT/pmc_f.log 2>&1 || { echo "FETCH_SIZE pass over bench.py failed / timed out"; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_w -o pmc -f csv -- python3 bench.py $PB > $OUT/pmc_w.log 2>&1 || { echo "WRITE_SIZE pass over bench.py failed / timed out"; exit 1; }
+python3 tools/pmc_traffic.py $OUT/pmc_f $OUT/pmc_w $OUT/${R}_pmc_bench_traffic.json > $OUT/${R}_pmc_bench_traffic.txt
+echo "profiles done"
