@@ -352,6 +352,101 @@ def train_steps(batches, state: Dict[str, torch.Tensor], spec: Spec, lr: float =
 
 
 # --------------------------------------------------------------------------- #
+# xdeepfm_pro: SFG decoder / loss, AutoDis                                     #
+# --------------------------------------------------------------------------- #
+@dataclass
+class ProSpec:
+    """The extra constructor arguments of deepctr/xdeepfm_pro/xdeepfm_pro.py:85-95."""
+    sfg_weight: float = 0.1
+    sfg_hidden_units: Tuple[int, ...] = (128, 64)
+    sfg_positive_only: bool = True
+    sfg_use_label_attention: bool = True
+    use_autodis: bool = False
+
+
+def autodis_forward(dense: torch.Tensor, state: Dict[str, torch.Tensor], prefix: str = "autodis_encoder.autodis.") -> torch.Tensor:
+    """deepctr/xdeepfm_pro/autodis.py:99-127: per feature Linear(1,nb) -> LeakyReLU(0.2) -> Linear(nb,nb) -> softmax(./temp)
+    -> mix of the bucket embeddings; [B, nd] -> [B, nd * D]."""
+    outs = []
+    for i in range(dense.shape[1]):
+        v = dense[:, i:i + 1]
+        h = F.leaky_relu(F.linear(v, state["%sbucket_projectors.%d.0.weight" % (prefix, i)],
+                                  state["%sbucket_projectors.%d.0.bias" % (prefix, i)]), 0.2)
+        sc = F.linear(h, state["%sbucket_projectors.%d.2.weight" % (prefix, i)], state["%sbucket_projectors.%d.2.bias" % (prefix, i)])
+        w = F.softmax(sc / state[prefix + "feature_temperatures"][i], dim=-1)
+        outs.append(torch.matmul(w, state[prefix + "meta_embeddings"][i]))
+    return torch.cat(outs, dim=-1)
+
+
+def sfg_loss(X: torch.Tensor, y: torch.Tensor, emb: torch.Tensor, state: Dict[str, torch.Tensor], spec: Spec,
+             pro: ProSpec) -> torch.Tensor:
+    """compute_sfg_loss + SFGDecoder.forward + SFGLoss.forward (deepctr/xdeepfm_pro/basemodel_sfg.py:420-476,
+    sfg_decoder.py:113-157, :257-311), dropout 0: label-aware gate, shared MLP, one vocabulary-wide softmax head per sparse
+    field with masked cross-entropy, one regression head with masked MSE."""
+    B = X.shape[0]
+    dv = dense_values(X, spec)
+    dec_in = torch.cat([emb.reshape(B, -1)] + ([dv] if dv is not None else []), dim=-1)      # sfg_decoder.py:113-136
+    labels = y.reshape(-1)
+    pre = "sfg_decoder."
+    if pro.sfg_use_label_attention:                                                           # sfg_decoder.py:184-206
+        lab = state[pre + "label_attention.label_embedding.weight"][labels.long()]
+        a = torch.relu(F.linear(torch.cat([dec_in, lab], dim=-1), state[pre + "label_attention.attention_net.0.weight"],
+                                state[pre + "label_attention.attention_net.0.bias"]))
+        gate = torch.sigmoid(F.linear(a, state[pre + "label_attention.attention_net.2.weight"],
+                                      state[pre + "label_attention.attention_net.2.bias"]))
+        dec_in = dec_in * gate
+    h = dec_in
+    for i in range(len(pro.sfg_hidden_units)):                                                # Linear, ReLU, Dropout(0) triples
+        h = torch.relu(F.linear(h, state["%sshared_layers.%d.weight" % (pre, 3 * i)], state["%sshared_layers.%d.bias" % (pre, 3 * i)]))
+    if pro.sfg_positive_only:                                                                 # sfg_decoder.py:262-268
+        mask = (labels == 1).float()
+        npos = mask.sum() + 1e-8
+    else:
+        mask = torch.ones_like(labels)
+        npos = float(B)
+    fi = spec.feature_index()
+    total_sparse = torch.zeros(())
+    for name in spec.sparse_names:                                                            # sfg_decoder.py:275-293
+        logits = F.linear(h, state["%ssparse_heads.%s.weight" % (pre, name)], state["%ssparse_heads.%s.bias" % (pre, name)])
+        ce = F.cross_entropy(logits, X[:, fi[name][0]].long(), reduction="none")
+        total_sparse = total_sparse + (ce * mask).sum() / npos
+    total_dense = torch.zeros(())
+    if spec.dense_names:                                                                      # sfg_decoder.py:295-304
+        preds = F.linear(h, state[pre + "dense_head.weight"], state[pre + "dense_head.bias"])
+        mse = F.mse_loss(preds, dv, reduction="none").mean(dim=-1)
+        total_dense = (mse * mask).sum() / npos
+    return total_sparse + total_dense
+
+
+def pro_forward_with_sfg(X, y, state, spec: Spec, pro: ProSpec, training: bool = True):
+    """xDeepFMPro.forward_with_sfg (deepctr/xdeepfm_pro/xdeepfm_pro.py:203-274) -> (y_pred [B,1], sfg loss or None)."""
+    emb = embed_gather(X, state, spec)
+    logit = linear_logit(X, state, spec)
+    if spec.cin_layer_size:
+        L = len(spec.cin_layer_size)
+        cin_out = cin_forward(emb, [state["cin.conv1ds.%d.weight" % i] for i in range(L)],
+                              [state["cin.conv1ds.%d.bias" % i] for i in range(L)], spec.cin_split_half, spec.cin_activation)
+        logit = logit + F.linear(cin_out, state["cin_linear.weight"])
+    if spec.dnn_hidden_units:
+        dv = dense_values(X, spec)
+        if pro.use_autodis and dv is not None:
+            dnn_in = torch.cat([emb.reshape(X.shape[0], -1), autodis_forward(dv, state)], dim=-1)   # xdeepfm_pro.py:236-242
+        else:
+            dnn_in = combined_dnn_input(emb, dv)
+        logit = logit + F.linear(dnn_forward(dnn_in, state, len(spec.dnn_hidden_units)), state["dnn_linear.weight"])
+    y_pred = torch.sigmoid(logit + state["out.bias"])
+    sfg = sfg_loss(X, y, emb, state, spec, pro) if (training and y is not None) else None
+    return y_pred, sfg
+
+
+def pro_total_loss(X, y, state, spec: Spec, pro: ProSpec):
+    """Objective of the BaseModelSFG.fit loop body (basemodel_sfg.py:327-343): BCE(sum) + L2 + sfg_weight * sfg_loss."""
+    y_pred, sfg = pro_forward_with_sfg(X, y, state, spec, pro, True)
+    loss = F.binary_cross_entropy(y_pred.squeeze(), y.squeeze(), reduction="sum")
+    return loss + regularization_loss(state, spec) + pro.sfg_weight * sfg, loss, sfg, y_pred
+
+
+# --------------------------------------------------------------------------- #
 # initialisation with the reference's RNG order                                #
 # --------------------------------------------------------------------------- #
 def init_state(spec: Spec, seed: int = 1024, init_std: float = 1e-4) -> Dict[str, torch.Tensor]:

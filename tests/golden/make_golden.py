@@ -296,6 +296,99 @@ def gen_fit_history():
     _save("fit_history", **arrays)
 
 
+PRO_CASES = [
+    # name,          vocab,                nd, D, cin,    dnn,     sfg hidden, B,  kw
+    ("pro_small",    [7, 5, 11, 3, 9, 4],  3,  4, (8, 6), (16, 8), (16, 8),    48, dict(sfg_positive_only=True, sfg_use_label_attention=True)),
+    ("pro_autodis",  [7, 5, 11, 3, 9, 4],  3,  4, (8, 6), (16, 8), (16, 8),    48, dict(sfg_positive_only=False, sfg_use_label_attention=False,
+                                                                                       use_autodis=True, autodis_buckets=6, sfg_weight=0.3)),
+    ("pro_nodense",  [13] * 22,            0,  8, (16, 8), (16,),  (12,),      32, dict()),
+]
+
+
+def gen_pro():
+    """deepctr/xdeepfm_pro: xDeepFMPro forward_with_sfg, every gradient of loss + reg + sfg_weight * sfg_loss, three Adam
+    steps of the BaseModelSFG.fit loop body (basemodel_sfg.py:317-349), predict; sfg_dropout = 0 (the dropout masks of two
+    generators cannot agree)."""
+    from deepctr.xdeepfm_pro.xdeepfm_pro import xDeepFMPro
+    for name, vocab, nd, D, cin, dnn, sfgh, B, kw in PRO_CASES:
+        sparse, dense, cols = _columns(vocab, nd, D)
+        model = xDeepFMPro(cols, cols, dnn_hidden_units=dnn, cin_layer_size=cin, l2_reg_dnn=1e-5, device="cpu",
+                           sfg_hidden_units=sfgh, sfg_dropout=0.0, **kw)
+        init = {k: _np(v) for k, v in model.state_dict().items()}
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if "embedding_dict" in k or k == "linear_model.weight" or k.startswith("dnn") or k == "cin_linear.weight" \
+                        or "sfg_decoder" in k or "autodis" in k:
+                    if "feature_temperatures" in k:
+                        p.copy_(1.0 + 0.2 * torch.rand(p.shape, generator=g))
+                    else:
+                        p.copy_(0.3 * torch.randn(p.shape, generator=g))
+        X, y = orc.synthetic_batch(3 * B, vocab, nd, seed=2026)
+        model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+        state0 = {k: _np(v) for k, v in model.state_dict().items()}
+        model.train()
+        Xt, yt = torch.from_numpy(X[:B]).float(), torch.from_numpy(y[:B]).float()
+        y_pred, info = model.forward_with_sfg(Xt, yt)
+        loss = torch.nn.functional.binary_cross_entropy(y_pred.squeeze(), yt.squeeze(), reduction="sum")
+        reg = model.get_regularization_loss()
+        sfg = info["sfg_loss"]
+        model.optim.zero_grad()
+        (loss + reg + model.aux_loss + model.sfg_weight * sfg).backward()
+        grads = {k: _np(p.grad) if p.grad is not None else np.zeros(tuple(p.shape), dtype=np.float32)
+                 for k, p in model.named_parameters()}
+        model.optim.zero_grad()
+        losses = []
+        for s in range(3):
+            xb = torch.from_numpy(X[s * B:(s + 1) * B]).float()
+            yb = torch.from_numpy(y[s * B:(s + 1) * B]).float()
+            yp, inf = model.forward_with_sfg(xb, yb)
+            model.optim.zero_grad()
+            l = torch.nn.functional.binary_cross_entropy(yp.squeeze(), yb.squeeze(), reduction="sum")
+            tot = l + model.get_regularization_loss() + model.aux_loss + model.sfg_weight * inf["sfg_loss"]
+            losses.append([l.item(), tot.item(), inf["sfg_loss"].item()])
+            tot.backward()
+            model.optim.step()
+        state3 = {k: _np(v) for k, v in model.state_dict().items()}
+        pred_after = model.predict([X[:, i] for i in range(X.shape[1])], batch_size=B)
+        arrays = dict(X=X, y=y, B=np.array(B), y_pred=_np(y_pred), loss=np.array(loss.item()), reg=np.array(reg.item()),
+                      sfg=np.array(sfg.item()), losses3=np.array(losses), pred_after=pred_after, vocab=np.array(vocab),
+                      n_dense=np.array(nd), emb_dim=np.array(D), cin=np.array(cin), dnn=np.array(dnn), sfg_hidden=np.array(sfgh),
+                      kw_keys=np.array(sorted(kw.keys())), kw_vals=np.array([float(kw[k]) for k in sorted(kw)]))
+        for k, v in init.items():
+            arrays["init:" + k] = v
+        for k, v in state0.items():
+            arrays["s0:" + k] = v
+        for k, v in grads.items():
+            arrays["g:" + k] = v
+        for k, v in state3.items():
+            arrays["s3:" + k] = v
+        _save(name, **arrays)
+    # History of BaseModelSFG.fit (basemodel_sfg.py:224-400): keys incl. sfg_loss
+    vocab, nd, D = [9, 6, 12, 5], 2, 4
+    sparse, dense, cols = _columns(vocab, nd, D)
+    model = xDeepFMPro(cols, cols, dnn_hidden_units=(8,), cin_layer_size=(6, 4), l2_reg_dnn=1e-5, device="cpu",
+                       sfg_hidden_units=(8, 6), sfg_dropout=0.0, sfg_weight=0.2)
+    model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+    for pg in model.optim.param_groups:
+        pg["lr"] = 1e-2
+    s0 = {k: _np(v) for k, v in model.state_dict().items()}
+    X, y = orc.synthetic_batch(256, vocab, nd, seed=79)      # full batches: a one-class tail batch makes sklearn raise in the reference loop
+    Xv, yv = orc.synthetic_batch(80, vocab, nd, seed=80)
+    names = sparse + dense
+    hist = model.fit({n: X[:, i] for i, n in enumerate(names)}, y, batch_size=64, epochs=2, verbose=2,
+                     validation_data=({n: Xv[:, i] for i, n in enumerate(names)}, yv), shuffle=False)
+    arrays = dict(X=X, y=y, Xv=Xv, yv=yv, vocab=np.array(vocab), n_dense=np.array(nd), emb_dim=np.array(D),
+                  hist_keys=np.array(sorted(hist.history.keys())),
+                  hist_vals=np.array([hist.history[k] for k in sorted(hist.history.keys())]),
+                  pred=model.predict({n: Xv[:, i] for i, n in enumerate(names)}, 32))
+    for k, v in s0.items():
+        arrays["s0:" + k] = v
+    for k, v in model.state_dict().items():
+        arrays["s1:" + k] = _np(v)
+    _save("pro_fit_history", **arrays)
+
+
 def gen_metrics():
     from sklearn.metrics import log_loss, roc_auc_score
     rng = np.random.default_rng(3)
@@ -307,8 +400,8 @@ def gen_metrics():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    gen_cin()
-    gen_attn()
-    gen_models()
-    gen_fit_history()
-    gen_metrics()
+    only = sys.argv[1:]                  # e.g. `make_golden.py pro` regenerates one family
+    for fam, fn in (("cin", gen_cin), ("attn", gen_attn), ("models", gen_models), ("fit", gen_fit_history),
+                    ("pro", gen_pro), ("metrics", gen_metrics)):
+        if not only or fam in only:
+            fn()

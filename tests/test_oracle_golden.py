@@ -106,3 +106,38 @@ def test_metrics_match_sklearn_golden():
 def test_cin_rejects_non_3d():
     with pytest.raises(ValueError):
         orc.cin_forward(torch.zeros(3, 4), [torch.zeros(2, 16, 1)], [torch.zeros(2)])
+
+
+def _pro_case(g):
+    vocab, nd, D = [int(v) for v in g["vocab"]], int(g["n_dense"]), int(g["emb_dim"])
+    kw = dict(zip([str(k) for k in g["kw_keys"]], [float(v) for v in g["kw_vals"]]))
+    names = ["C%d" % (i + 1) for i in range(len(vocab))]
+    dnames = ["I%d" % (i + 1) for i in range(nd)]
+    spec = orc.Spec(names, vocab, dnames, D, tuple(int(v) for v in g["cin"]), True, "relu", tuple(int(v) for v in g["dnn"]),
+                    l2_reg_dnn=1e-5)
+    pro = orc.ProSpec(sfg_weight=kw.get("sfg_weight", 0.1), sfg_hidden_units=tuple(int(v) for v in g["sfg_hidden"]),
+                      sfg_positive_only=bool(kw.get("sfg_positive_only", 1.0)),
+                      sfg_use_label_attention=bool(kw.get("sfg_use_label_attention", 1.0)), use_autodis=bool(kw.get("use_autodis", 0.0)))
+    return spec, pro
+
+
+@pytest.mark.parametrize("name", golden_names("pro_"))
+def test_pro_oracle_vs_reference_golden(name):
+    """deepctr/xdeepfm_pro (SFG decoder, label-aware gate, masked CE / MSE, AutoDis): forward, sfg loss, every gradient of
+    BCE + L2 + sfg_weight * sfg_loss against the values the reference produced (tests/golden/make_golden.py pro)."""
+    if name == "pro_fit_history":
+        pytest.skip("History of the fit loop: checked on the GPU path")
+    g = load_golden(name)
+    spec, pro = _pro_case(g)
+    B = int(g["B"])
+    state = {k[3:]: T(g[k]).clone().requires_grad_(True) for k in g if k.startswith("s0:")}
+    X, y = T(g["X"][:B]).float(), T(g["y"][:B]).float()
+    tot, loss, sfg, y_pred = orc.pro_total_loss(X, y, state, spec, pro)
+    np.testing.assert_allclose(y_pred.detach().numpy(), g["y_pred"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(loss.item(), float(g["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(sfg.item(), float(g["sfg"]), rtol=1e-5)
+    tot.backward()
+    for k, v in state.items():
+        want = g["g:" + k]
+        got = v.grad.numpy() if v.grad is not None else np.zeros_like(want)
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-6 * max(1.0, float(np.abs(want).max())), err_msg=k)

@@ -408,6 +408,12 @@ class BaseModel(nn.Module):
             if self._plan is not None and not prev:
                 self._plan.arena_on = False
 
+    def _with_step_extra(self, total):
+        """A model's `_loss_forward` may leave a further differentiable term of the step's objective in `_step_extra`
+        (xDeepFMPro: sfg_weight * sfg_loss, basemodel_sfg.py:343) and a value for the epoch log in `_step_log`."""
+        extra = self.__dict__.get("_step_extra")
+        return total if extra is None else total + extra.reshape(total.shape)
+
     def _unit_grad(self, loss):
         """Root gradient of a backward pass, cached: autograd would otherwise fill a fresh ones tensor every step.
         A rank that holds only a stand-in row (a global batch with fewer rows than ranks, dist.RowParallel.shard)
@@ -431,6 +437,7 @@ class BaseModel(nn.Module):
         try:
             y_pred, loss = self._loss_forward(x, y)
             root = loss if self._aux_unset else loss + self.aux_loss
+            root = self._with_step_extra(root)
             root.backward(self._unit_grad(root))
             stash = plan.stash
         finally:
@@ -452,6 +459,8 @@ class BaseModel(nn.Module):
         self.optim.arm_l2(*fuse)
         self.optim.step()
         total_loss = loss if self._aux_unset else loss + self.aux_loss.detach()
+        if self.__dict__.get("_step_extra") is not None:
+            total_loss = total_loss + self._step_extra.detach().reshape(total_loss.shape)
         if self.optim.l2_value is not None:
             total_loss = total_loss + self.optim.l2_value
         return y_pred, loss, total_loss.detach()
@@ -481,12 +490,13 @@ class BaseModel(nn.Module):
             # the term is identical on every replica and must count once)
             self.optim.arm_l2(*fuse)
             total_loss = loss if self._aux_unset else loss + self.aux_loss
+            total_loss = self._with_step_extra(total_loss)
             total_loss.backward(self._unit_grad(total_loss))
             if dp is not None:
                 dp.reduce_dense_grads(self)
         elif dp is None:
             reg_loss = self.get_regularization_loss(_defer_tables=True)
-            total_loss = loss + reg_loss + self.aux_loss
+            total_loss = self._with_step_extra(loss + reg_loss + self.aux_loss)
             total_loss.backward()
         else:
             # Data-loss gradients are SUMMED over ranks (the loss is a sum over the global batch); the L2
@@ -678,9 +688,12 @@ class BaseModel(nn.Module):
                     # sync per step that leaves the GPU idle while the next step is being enqueued.  The values are
                     # parked on the device instead and read once per epoch, summed in the same order in double.
                     if loss_log is None or loss_log.device != total_loss.device:
-                        loss_log = torch.empty((steps_per_epoch + 1, 2), dtype=torch.float32, device=total_loss.device)
+                        loss_log = torch.empty((steps_per_epoch + 1, 3), dtype=torch.float32, device=total_loss.device)
                     loss_log[step_no, 0:1].copy_(loss.detach().reshape(1))
                     loss_log[step_no, 1:2].copy_(total_loss.detach().reshape(1))
+                    step_log = self.__dict__.get("_step_log")           # (name, value) a model wants summed per epoch
+                    if step_log is not None:
+                        loss_log[step_no, 2:3].copy_(step_log[1].reshape(1))
                     step_no += 1
                     if verbose > 0:
                         yt, yp = yd, y_pred
@@ -717,6 +730,12 @@ class BaseModel(nn.Module):
                     total_loss_epoch += v
             self._raise_on_bad_ids()          # deferred IndexError of the epoch's gathers (host is in sync here anyway)
             epoch_logs["loss"] = total_loss_epoch / sample_num
+            step_log = self.__dict__.get("_step_log")
+            if step_log is not None and step_no:     # e.g. "sfg_loss": sum of the steps' values / sample_num (basemodel_sfg.py:365-366)
+                extra_sum = 0.0
+                for v in loss_log[:step_no, 2].tolist():
+                    extra_sum += v
+                epoch_logs[step_log[0]] = extra_sum / sample_num
             for name, k in logged.items():
                 vals = metric_log[:step_no, k].tolist()
                 if name == "auc" and any(v != v for v in vals):
@@ -730,6 +749,8 @@ class BaseModel(nn.Module):
                     epoch_logs["val_" + name] = val
             if verbose > 0 and (dp is None or dp.rank == 0):
                 msg = "{0}s - loss: {1: .4f}".format(int(time.time() - t_epoch), epoch_logs["loss"])
+                if "sfg_loss" in epoch_logs:
+                    msg += " - sfg_loss: {0: .4f}".format(epoch_logs["sfg_loss"])
                 for name in self.metrics:
                     msg += " - " + name + ": {0: .4f}".format(epoch_logs[name])
                 if do_validation:

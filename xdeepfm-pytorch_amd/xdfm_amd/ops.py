@@ -678,6 +678,74 @@ class Head(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------------- #
+# vocabulary-wide softmax cross-entropy (SFG decoder heads)                                       #
+# --------------------------------------------------------------------------------------------- #
+VOCAB_TILE_BYTES = 256 << 20        # logits of one vocabulary tile kept at a time ([rows, tile] fp32)
+
+
+class VocabSoftmaxCE(torch.autograd.Function):
+    """ce[r] = logsumexp_v(h_r . W_v + b_v) - (h_r . W_t + b_t), t = target[r]: nn.Linear(K, V) followed by
+    F.cross_entropy(reduction='none') (deepctr/xdeepfm_pro/sfg_decoder.py:146-149, :277-283) WITHOUT the [rows, V]
+    logits: the vocabulary is walked in tiles with an online log-sum-exp, and the backward recomputes each tile
+    (softmax - onehot) for the three products.  At Criteo-scale vocabularies the logits of one field would be
+    4096 x 10 M x 4 B = 164 GB.  The tile GEMMs are library GEMMs (hipBLASLt); everything stays on the device.
+    hidden [rows, K], W [V, K], b [V], target [rows] (ids as float or integer, truncated like Tensor.long())."""
+
+    @staticmethod
+    def _tile(rows, V):
+        return int(max(1024, min(V, VOCAB_TILE_BYTES // (4 * max(rows, 1)))))
+
+    @staticmethod
+    def forward(ctx, hidden, W, b, target):
+        rows, V = hidden.shape[0], W.shape[0]
+        tgt = target.long()
+        T = VocabSoftmaxCE._tile(rows, V)
+        m = torch.full((rows,), float("-inf"), dtype=torch.float32, device=hidden.device)
+        ssum = torch.zeros(rows, dtype=torch.float32, device=hidden.device)
+        for v0 in range(0, V, T):
+            z = torch.addmm(b[v0:v0 + T], hidden, W[v0:v0 + T].t())
+            m_new = torch.maximum(m, z.max(dim=1).values)
+            ssum = ssum * torch.exp(m - m_new) + torch.exp(z - m_new[:, None]).sum(dim=1)
+            m = m_new
+        lse = m + torch.log(ssum)
+        zt = (hidden * W.index_select(0, tgt)).sum(dim=1) + b.index_select(0, tgt)
+        ctx.save_for_backward(hidden, W, b, tgt, lse)
+        return lse - zt
+
+    @staticmethod
+    def backward(ctx, g):
+        hidden, W, b, tgt, lse = ctx.saved_tensors
+        rows, V = hidden.shape[0], W.shape[0]
+        T = VocabSoftmaxCE._tile(rows, V)
+        g = g.contiguous()
+        dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
+        dh = torch.zeros_like(hidden) if ctx.needs_input_grad[0] else None
+        for v0 in range(0, V, T):
+            z = torch.addmm(b[v0:v0 + T], hidden, W[v0:v0 + T].t())
+            dz = torch.exp(z - lse[:, None]) * g[:, None]                # g * softmax
+            if dW is not None:
+                torch.mm(dz.t(), hidden, out=dW[v0:v0 + T])
+            if db is not None:
+                torch.sum(dz, dim=0, out=db[v0:v0 + T])
+            if dh is not None:
+                dh.addmm_(dz, W[v0:v0 + T])
+        # - g * onehot(target)
+        if dW is not None:
+            dW.index_add_(0, tgt, -(g[:, None] * hidden))
+        if db is not None:
+            db.index_add_(0, tgt, -g)
+        if dh is not None:
+            dh.sub_(g[:, None] * W.index_select(0, tgt))
+        return dh, dW, db, None
+
+
+def vocab_softmax_ce(hidden, W, b, target):
+    _need_cuda(hidden, "decoder hidden layer")
+    return VocabSoftmaxCE.apply(hidden, W, b, target)
+
+
+# --------------------------------------------------------------------------------------------- #
 # L2 regulariser                                                                                 #
 # --------------------------------------------------------------------------------------------- #
 class L2Plan:
