@@ -29,6 +29,7 @@
  * xdfm_relu_bwd_colsum.
  * ABI 4: K2 is a sorted, segmented, exact reduce (no atomics; same entry points), xdfm_adam_step_lr (learning rate
  * from a device scalar), read-only options "last_fwd_kernel" / "last_bwx_kernel" / "last_bww_kernel".
+ * ABI 5: attention dropout in K5 (p_drop, drop_seed on xdfm_cin_attn_pool_fwd/bwd; xdfm_cin_attn_dropout_mask).
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -40,7 +41,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 4
+#define XDFM_ABI_VERSION 5
 
 enum {
     XDFM_OK = 0,
@@ -203,14 +204,26 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
  * ml_save [n_layers][B][S][nh][2] (softmax max, 1/sum): written by fwd, read by bwd.
  * bwd: dout [B][D]; dfm [S][B*D] is overwritten; dtheta (same layout as theta) is ACCUMULATED into with
  * fp32 atomics and must be zeroed by the caller.  S <= 1024.
+ * p_drop, drop_seed: attention dropout (cin_attention.py:86, nn.Dropout on the softmax output, training mode
+ * only).  p_drop = 0 (drop_seed may be NULL) is the reference's default and the evaluation path.  With
+ * 0 < p_drop < 1 every attention weight is kept with probability 1-p_drop and scaled by 1/(1-p_drop); the keep
+ * bit is a hash of (*drop_seed, example, layer, head, query, key) -- drop_seed is a DEVICE 64-bit scalar so a
+ * captured graph draws a new mask per replay -- and nothing is stored: bwd must be given the same p_drop and
+ * seed value as the fwd whose buffers it reads.  The stream of bits is not torch's Philox stream; like the
+ * reference's CPU and CUDA generators, two back ends agree in distribution, not bit for bit.
  */
 size_t xdfm_cin_attn_theta_elems(int D, int n_layers, int use_ln);
 int xdfm_cin_attn_pool_fwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
                            const float* theta, float* out, float* tok_save, float* o_save, float* ml_save,
-                           void* stream);
+                           float p_drop, const unsigned long long* drop_seed, void* stream);
 int xdfm_cin_attn_pool_bwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
                            const float* theta, const float* tok_save, const float* o_save, const float* ml_save,
-                           const float* dout, float* dfm, float* dtheta, void* stream);
+                           const float* dout, float* dfm, float* dtheta, float p_drop,
+                           const unsigned long long* drop_seed, void* stream);
+/* keep[n_layers][B][nh][S(query)][S(key)] (1 = kept): the mask the two calls above generate for this seed.
+ * Test hook: lets a CPU oracle apply the same mask where the reference applies nn.Dropout. */
+int xdfm_cin_attn_dropout_mask(int B, int S, int nh, int n_layers, float p_drop, const unsigned long long* drop_seed,
+                               unsigned char* keep, void* stream);
 
 /* ------------------------------------------------------------------ L2 regulariser (K6)
  * replaces: deepctr/models/basemodel.py:412-428 (per-tensor square / mul / sum / add loop over

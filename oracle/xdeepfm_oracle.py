@@ -200,8 +200,10 @@ def cin_forward(x0, weights, biases, split_half=True, activation="relu") -> torc
 # --------------------------------------------------------------------------- #
 # attention pooling over the CIN feature maps                                  #
 # --------------------------------------------------------------------------- #
-def mhsa(x: torch.Tensor, wq, wk, wv, wo, num_heads: int) -> torch.Tensor:
-    """deepctr/layers/cin_attention.py:63-97 (bias-free projections, dropout p=0)."""
+def mhsa(x: torch.Tensor, wq, wk, wv, wo, num_heads: int, keep=None, p_drop: float = 0.0) -> torch.Tensor:
+    """deepctr/layers/cin_attention.py:63-97 (bias-free projections).  keep: optional [B, heads, S, S] 0/1 mask
+    standing for the draw of `self.dropout(attn_weights)` (:86, training mode): kept weights are scaled by
+    1/(1-p_drop) as nn.Dropout does; None = evaluation mode / p = 0."""
     B, S, E = x.shape
     nh = valid_num_heads(E, num_heads)
     hd = E // nh
@@ -210,6 +212,8 @@ def mhsa(x: torch.Tensor, wq, wk, wv, wo, num_heads: int) -> torch.Tensor:
     v = F.linear(x, wv).view(B, S, nh, hd).transpose(1, 2)
     scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(hd)   # :84
     probs = F.softmax(scores, dim=-1)                                # :85
+    if keep is not None:
+        probs = probs * keep.to(probs.dtype) / (1.0 - p_drop)        # :86
     o = torch.matmul(probs, v)                                       # :89
     o = o.transpose(1, 2).contiguous().view(B, S, E)                 # :92
     return F.linear(o, wo)                                           # :95
@@ -222,9 +226,11 @@ def attention_pooling(x: torch.Tensor, w1, b1, w2) -> torch.Tensor:
     return torch.sum(a * x, dim=1)
 
 
-def cin_attention_forward(x0, state: Dict[str, torch.Tensor], prefix: str, spec: Spec) -> torch.Tensor:
+def cin_attention_forward(x0, state: Dict[str, torch.Tensor], prefix: str, spec: Spec, keep=None,
+                          p_drop: float = 0.0) -> torch.Tensor:
     """CINAttention.forward (deepctr/layers/cin_attention.py:239-318) -> [B, featuremap_num]
-    or CINAttentionV2.forward (:399-466) -> [B, D] when spec.variant == 'attn_v2'."""
+    or CINAttentionV2.forward (:399-466) -> [B, D] when spec.variant == 'attn_v2'.
+    keep: optional [n_layers, B, heads, S, S] attention-dropout masks (see mhsa)."""
     L = len(spec.cin_layer_size)
     W = [state["%sconv1ds.%d.weight" % (prefix, i)] for i in range(L)]
     Bs = [state["%sconv1ds.%d.bias" % (prefix, i)] for i in range(L)]
@@ -232,7 +238,8 @@ def cin_attention_forward(x0, state: Dict[str, torch.Tensor], prefix: str, spec:
     E = fm.shape[-1]
     if spec.variant == "attn":
         a = mhsa(fm, state[prefix + "mhsa.W_q.weight"], state[prefix + "mhsa.W_k.weight"],
-                 state[prefix + "mhsa.W_v.weight"], state[prefix + "mhsa.W_o.weight"], spec.num_heads)
+                 state[prefix + "mhsa.W_v.weight"], state[prefix + "mhsa.W_o.weight"], spec.num_heads,
+                 None if keep is None else keep[0], p_drop)
         if spec.use_residual:
             a = a + fm                                                           # :305-306
         if spec.use_layer_norm:
@@ -247,7 +254,8 @@ def cin_attention_forward(x0, state: Dict[str, torch.Tensor], prefix: str, spec:
         for l in range(spec.num_attn_layers):                                    # :452-461
             p = "%smhsa_layers.%d." % (prefix, l)
             a = mhsa(r, state[p + "W_q.weight"], state[p + "W_k.weight"],
-                     state[p + "W_v.weight"], state[p + "W_o.weight"], spec.num_heads)
+                     state[p + "W_v.weight"], state[p + "W_o.weight"], spec.num_heads,
+                     None if keep is None else keep[l], p_drop)
             if spec.use_residual:
                 a = a + r
             if spec.use_layer_norm:

@@ -206,3 +206,35 @@ def test_lazy_rows_opt_in_updates_only_touched_rows():
     for key in sl:
         if "embedding_dict" not in key:
             np.testing.assert_allclose(sl[key].cpu().numpy(), sd[key].cpu().numpy(), rtol=1e-5, atol=1e-7, err_msg=key)
+
+
+def test_attention_dropout_draws_a_new_mask_on_every_graph_replay():
+    """cin_attn_dropout > 0 under the captured train step: the seed of K5's mask is a device scalar drawn from torch's
+    generator inside the capture, so a replay advances it (a host-side seed would be baked into the graph and every
+    step would drop the same weights).  Same batch, zero learning rate: the losses of consecutive replays differ, and
+    re-seeding torch repeats the sequence.  Evaluation ignores the rate."""
+    from deepctr.models import xDeepFMAttention
+    dev = _dev()
+    torch.manual_seed(5)
+    model, step = _model(dev, True, cls=xDeepFMAttention, cin_attn_dropout=0.5, cin_num_heads=2)
+    with torch.no_grad():                       # the default init (std 1e-4) makes the attention branch vanish in the loss
+        for k, p in model.named_parameters():
+            if "cin." in k or "cin_linear" in k:
+                p.mul_(3000.0 if p.abs().max() < 1e-2 else 1.0)
+    for g in model.optim.param_groups:
+        g["lr"] = 0.0
+    X, y = _batch(0)
+    X, y = X.to(dev), y.to(dev)
+
+    def losses(n):
+        return [float(model.train_on_batch(X, y)[1]) for _ in range(n)]
+    torch.manual_seed(11)
+    a = losses(6)
+    assert step.replays >= 3 and not step.disabled
+    assert len(set(a[2:])) == len(a[2:]), a          # replayed steps: all different masks
+    model.eval()
+    with torch.no_grad():
+        e1 = model(X).clone()
+        e2 = model(X)
+    assert torch.equal(e1, e2)
+    model.train()

@@ -61,7 +61,7 @@ def cin_math(request):
 def test_native_library_is_loaded():
     from xdfm_amd import _lib
     lib = _lib.load()
-    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 5
     assert lib.xdfm_device_count() >= 1
     with open("/proc/self/maps") as f:
         assert "libxdfm_hip.so" in f.read()
@@ -861,6 +861,183 @@ def test_attention_kernel_vs_float64_oracle(variant, B, m, D, ls, heads, ln, res
     scaled(xg.grad, x64.grad, "dx")
     for k, p in layer.named_parameters():
         scaled(p.grad, st64["cin." + k].grad, k)
+
+
+@pytest.mark.parametrize("variant,p_drop", [("attn", 0.0), ("attn_v2", 0.0), ("attn", 0.2)])
+def test_full_size_attention_rows_vs_oracle_subset(variant, p_drop):
+    """K5 at BASELINE config 3's full size (B=4096, m=26, D=16, cin=(256,128,128) -> S=320 tokens, 4 heads; the
+    2048-workgroup grid-stride path of the backward).  Examples are independent: 24 rows of the full launch are
+    compared with the float64 oracle on just those rows; with a gout that is zero outside the subset the parameter
+    gradients of the full batch equal the oracle's on the subset (linearity), and untouched examples get exactly 0."""
+    from deepctr.layers import CINAttention, CINAttentionV2
+    from oracle import xdeepfm_oracle as orc
+    from xdfm_amd import ops
+    dev = _dev()
+    B, m, D, ls, heads, nl = 4096, 26, 16, (256, 128, 128), 4, (2 if variant == "attn_v2" else 1)
+    torch.manual_seed(17)
+    if variant == "attn":
+        layer = CINAttention(m, D, ls, "relu", True, heads, p_drop, True, True, 0.0, 1024, "cpu")
+    else:
+        layer = CINAttentionV2(m, D, ls, "relu", True, heads, p_drop, True, True, nl, 0.0, 1024, "cpu")
+    with torch.no_grad():
+        for k, p in layer.named_parameters():
+            if "layer_norm" in k or k.endswith("attention.0.bias"):
+                p.add_(0.3 * torch.randn(p.shape))
+    x = torch.randn(B, m, D) * 0.5
+    rows = torch.randperm(B)[:24]
+    rows[0], rows[1] = 0, B - 1
+    spec = orc.Spec(["f%d" % i for i in range(m)], [1] * m, [], D, ls, True, "relu", (), variant, heads, True, True, nl)
+    params = {k: p.detach().clone() for k, p in layer.named_parameters()}
+    layer = layer.to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg)
+    keep = None
+    if p_drop > 0:
+        S = sum(h // 2 for h in ls[:-1]) + ls[-1]
+        keep = _attn_keep_mask(B, S, heads, nl, p_drop, ops.AttnPool.last_drop_seed, dev)[:, rows.to(dev)].cpu()
+    st64 = {"cin." + k: p.double().requires_grad_(True) for k, p in params.items()}
+    xs = x[rows].double().requires_grad_(True)
+    want = orc.cin_attention_forward(xs, st64, "cin.", spec, keep=keep, p_drop=p_drop)
+    gsub = torch.randn(want.shape)
+    (want * gsub.double()).sum().backward()
+    wn = want.detach().numpy()
+    close(out[rows.to(dev)], wn, rtol=1e-4, atol=1e-5 * float(np.abs(wn).max()) + 1e-7, msg="out rows")
+    gout = torch.zeros(B, want.shape[1])
+    gout[rows] = gsub
+    (out * gout.to(dev)).sum().backward()
+
+    def scaled(got, ref, name):
+        ref = ref.numpy()
+        close(got, ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 5e-6, msg=name)
+    scaled(xg.grad[rows.to(dev)], xs.grad, "dx rows")
+    mask = torch.ones(B, dtype=torch.bool)
+    mask[rows] = False
+    assert float(xg.grad[mask.to(dev)].abs().max()) == 0.0
+    for k, p in layer.named_parameters():
+        scaled(p.grad, st64["cin." + k].grad, k)
+
+
+def _attn_keep_mask(B, S, nh, n_layers, p_drop, seed, dev):
+    """The keep bits K5 generates for `seed` (device int64 scalar), through the C ABI: [n_layers, B, nh, S, S] uint8."""
+    from xdfm_amd import _lib
+    lib = _lib.load()
+    keep = torch.empty((n_layers, B, nh, S, S), dtype=torch.uint8, device=dev)
+    _lib.check(lib.xdfm_cin_attn_dropout_mask(B, S, nh, n_layers, float(p_drop), seed.data_ptr(), keep.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "mask")
+    torch.cuda.synchronize()
+    return keep
+
+
+@pytest.mark.parametrize("variant,B,m,D,ls,heads,ln,res,nl,p_drop", [
+    ("attn", 5, 26, 16, (64, 48), 4, True, True, 1, 0.3),
+    ("attn_v2", 4, 22, 16, (48, 40), 2, True, False, 2, 0.5),
+    ("attn", 2, 26, 16, (256, 128, 128), 4, True, True, 1, 0.1),   # S = 320
+    ("attn_v2", 3, 9, 32, (24, 20), 8, True, True, 2, 0.25),
+    ("attn", 3, 6, 10, (12, 10), 4, False, True, 1, 0.9),
+])
+def test_attention_dropout_forward_and_backward_use_one_mask(variant, B, m, D, ls, heads, ln, res, nl, p_drop):
+    """cin_attn_dropout > 0 in training mode (cin_attention.py:86).  K5 stores no mask: forward and both backward passes
+    regenerate it from (seed, example, layer, head, query, key).  The mask K5 used is read back through
+    xdfm_cin_attn_dropout_mask and handed to the float64 oracle, which applies it where the reference applies
+    nn.Dropout: output, dx and every parameter gradient must agree -- which they only do when the three passes of the
+    kernel see the SAME bits.  (The bit stream itself is not torch's Philox stream: like the reference on CPU vs CUDA,
+    the draw matches in distribution only; see test_attention_dropout_mask_statistics.)"""
+    from deepctr.layers import CINAttention, CINAttentionV2
+    from oracle import xdeepfm_oracle as orc
+    from xdfm_amd import ops
+    dev = _dev()
+    torch.manual_seed(B + m + D)
+    if variant == "attn":
+        layer = CINAttention(m, D, ls, "relu", True, heads, p_drop, ln, res, 0.0, 1024, "cpu")
+        nl = 1
+    else:
+        layer = CINAttentionV2(m, D, ls, "relu", True, heads, p_drop, ln, res, nl, 0.0, 1024, "cpu")
+    with torch.no_grad():
+        for k, p in layer.named_parameters():
+            if "layer_norm" in k or k.endswith("attention.0.bias"):
+                p.add_(0.3 * torch.randn(p.shape))
+    x = torch.randn(B, m, D) * 0.7
+    spec = orc.Spec(["f%d" % i for i in range(m)], [1] * m, [], D, tuple(ls), True, "relu", (), variant, heads, ln,
+                    res, nl)
+    params = {k: p.detach().clone() for k, p in layer.named_parameters()}
+    layer = layer.to(dev).train()
+    xg = x.to(dev).requires_grad_(True)
+    out = layer(xg)
+    seed = ops.AttnPool.last_drop_seed
+    assert seed is not None
+    S = sum(h // 2 for h in ls[:-1]) + ls[-1]
+    nh = orc.valid_num_heads(D, heads)
+    keep = _attn_keep_mask(B, S, nh, nl, p_drop, seed, dev).cpu()
+    st64 = {"cin." + k: p.double().requires_grad_(True) for k, p in params.items()}
+    x64 = x.double().requires_grad_(True)
+    want = orc.cin_attention_forward(x64, st64, "cin.", spec, keep=keep, p_drop=p_drop)
+    gout = torch.randn(want.shape)
+    (want * gout.double()).sum().backward()
+    wn = want.detach().numpy()
+    close(out, wn, rtol=1e-4, atol=1e-5 * float(np.abs(wn).max()) + 1e-7, msg="out")
+    (out * gout.to(dev)).sum().backward()
+
+    def scaled(got, ref, name):
+        ref = ref.numpy()
+        close(got, ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 5e-6, msg=name)
+    scaled(xg.grad, x64.grad, "dx")
+    for k, p in layer.named_parameters():
+        scaled(p.grad, st64["cin." + k].grad, k)
+    # evaluation mode ignores the rate (nn.Dropout is the identity under .eval())
+    layer.eval()
+    with torch.no_grad():
+        ev = layer(x.to(dev))
+    want_eval = orc.cin_attention_forward(x.double(), {k: v.detach() for k, v in st64.items()}, "cin.", spec).numpy()
+    close(ev, want_eval, rtol=1e-4, atol=1e-5 * float(np.abs(want_eval).max()) + 1e-7, msg="eval")
+
+
+def test_attention_dropout_mask_statistics():
+    """The keep bits behave like nn.Dropout's Bernoulli(1-p) draw: rate within 5 sigma for every (layer, head) plane,
+    no correlation between planes / examples / neighbouring keys, a new mask for a new seed, the same mask for the same
+    seed; and the model draws a different seed on every call while torch.manual_seed repeats a run."""
+    dev = _dev()
+    B, S, nh, L = 64, 80, 4, 2
+    for p_drop in (0.1, 0.5, 0.8):
+        s1 = torch.tensor([1234567891011], dtype=torch.int64, device=dev)
+        s2 = torch.tensor([1234567891012], dtype=torch.int64, device=dev)
+        k1 = _attn_keep_mask(B, S, nh, L, p_drop, s1, dev)
+        assert torch.equal(k1, _attn_keep_mask(B, S, nh, L, p_drop, s1, dev))
+        k2 = _attn_keep_mask(B, S, nh, L, p_drop, s2, dev)
+        a = k1.double().cpu().numpy()
+        b = k2.double().cpu().numpy()
+        q = 1.0 - p_drop
+        n_plane = B * S * S
+        rates = a.mean(axis=(1, 3, 4))                                      # [L, nh]
+        assert np.all(np.abs(rates - q) < 5 * np.sqrt(q * p_drop / n_plane)), (p_drop, rates)
+        per_example = a.mean(axis=(0, 2, 3, 4))
+        assert np.all(np.abs(per_example - q) < 5 * np.sqrt(q * p_drop / (L * nh * S * S)))
+
+        def corr(u, v):
+            u = u.ravel() - u.mean()
+            v = v.ravel() - v.mean()
+            return float((u * v).mean() / np.sqrt((u * u).mean() * (v * v).mean()))
+        n = a[0, :, 0].size
+        lim = 5.0 / np.sqrt(n)
+        assert abs(corr(a[0, :, 0], a[0, :, 1])) < lim                       # heads
+        assert abs(corr(a[0, :, 0], a[1, :, 0])) < lim                       # layers
+        assert abs(corr(a[0, :B // 2], a[0, B // 2:])) < 5.0 / np.sqrt(a[0, :B // 2].size)   # examples
+        assert abs(corr(a[..., :-1], a[..., 1:])) < 5.0 / np.sqrt(a[..., 1:].size)      # neighbouring keys
+        assert abs(corr(a[..., :-1, :], a[..., 1:, :])) < 5.0 / np.sqrt(a[..., 1:, :].size)  # neighbouring queries
+        assert abs(corr(a, b)) < 5.0 / np.sqrt(a.size)                       # seeds
+    from deepctr.layers import CINAttention
+    from xdfm_amd import ops
+    torch.manual_seed(3)
+    layer = CINAttention(6, 8, (12, 10), "relu", True, 2, 0.4, True, True, 0.0, 1024, "cpu").to(dev).train()
+    x = torch.randn(4, 6, 8, device=dev)
+    torch.manual_seed(77)
+    o1 = layer(x)
+    sd1 = int(ops.AttnPool.last_drop_seed.item())
+    o2 = layer(x)
+    sd2 = int(ops.AttnPool.last_drop_seed.item())
+    assert sd1 != sd2 and not torch.equal(o1, o2)
+    torch.manual_seed(77)
+    o3 = layer(x)
+    assert int(ops.AttnPool.last_drop_seed.item()) == sd1 and torch.equal(o1, o3)
 
 
 def test_full_size_logloss_auc_vs_cpu_path():

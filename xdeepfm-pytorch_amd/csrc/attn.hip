@@ -116,6 +116,29 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Attention dropout (cin_attention.py:86: `self.dropout(attn_weights)` between the softmax and P.V).  The keep mask
+// is a counter-based hash of (seed, example, layer, head, query, key): nothing is stored, the backward regenerates
+// the same bits.  One 32-bit finaliser per element on top of a per-(example, layer, head, query) row key.
+struct AttnDrop {
+    const unsigned long long* seed;     // device scalar, drawn per forward call from torch's generator
+    unsigned thresh;                    // keep iff hash >= thresh   (thresh = p * 2^32)
+    float keep_scale;                   // 1 / (1 - p)
+};
+__device__ __forceinline__ unsigned drop_mix(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned drop_row_key(unsigned long long seed, int b, int layer, int n_layers, int h, int nh,
+                                                 int q) {
+    const unsigned w0 = ((unsigned)b * (unsigned)n_layers + (unsigned)layer) * (unsigned)nh + (unsigned)h;
+    const unsigned x = drop_mix((unsigned)seed ^ (w0 * 0x9E3779B1U));
+    return drop_mix(x + (unsigned)(seed >> 32) + (unsigned)q * 0x85EBCA77U);
+}
+__device__ __forceinline__ float drop_keep(unsigned row_key, int t, unsigned thresh, float keep_scale) {
+    return drop_mix(row_key + (unsigned)t * 0x9E3779B1U) >= thresh ? keep_scale : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // scores of one query against key row t, all heads
 template <int D, int NH>
 __device__ __forceinline__ void head_scores(const float (&q)[D], const float (&k)[D], float scale, float (&sc)[NH]) {
@@ -133,10 +156,11 @@ __device__ __forceinline__ void head_scores(const float (&q)[D], const float (&k
 // padded pitch: every thread reads its own row) and is replaced there by the layer's output
 // (post residual / LayerNorm), which is also returned in a.  Ks/Vs: [S][D] LDS; WT: this layer's
 // weights in LDS, matrices transposed.  mx / ls: softmax statistics of the thread's query row.
-template <int D, int NH>
+template <int D, int NH, bool DROP>
 __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], float (&mx)[NH], float (&ls)[NH],
                                                float* Xs, float* Ks, float* Vs, const float* WT, int S, bool live,
-                                               int use_ln, int use_res) {
+                                               int use_ln, int use_res, const unsigned (&rk)[NH], unsigned thresh,
+                                               float keep_scale) {
     constexpr int HD = D / NH;
     constexpr int XP = D + 1;
     const int s = threadIdx.x;
@@ -178,9 +202,10 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const float p = __expf(sc[h] - mx[h]);
-            ls[h] += p;
+            ls[h] += p;                                  // the softmax normaliser is over ALL keys; the mask comes after
+            const float pm = DROP ? p * drop_keep(rk[h], t, thresh, keep_scale) : p;
 #pragma unroll
-            for (int e = 0; e < HD; ++e) o[h * HD + e] = fmaf(p, v[h * HD + e], o[h * HD + e]);
+            for (int e = 0; e < HD; ++e) o[h * HD + e] = fmaf(pm, v[h * HD + e], o[h * HD + e]);
         }
     }
     // a = (residual x) + W_o (o / l)
@@ -215,11 +240,11 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
 
 // TB = compile-time bound of the block size (round_up(S, 64) threads): 512 leaves 256 VGPRs per lane
 // (2 waves/SIMD), 1024 only 128 -- the host picks the smallest that covers S.
-template <int D, int NH, int TB>
+template <int D, int NH, int TB, bool DROP>
 __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
     const float* __restrict__ fm, long N, int B, int S, int n_layers, int use_ln, int use_res,
     const float* __restrict__ theta, float* __restrict__ out, float* __restrict__ tok_save,
-    float* __restrict__ o_save, float* __restrict__ ml_save) {
+    float* __restrict__ o_save, float* __restrict__ ml_save, AttnDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int XP = D + 1;
     float* Ks = smem;                                    // [S][D]
@@ -244,7 +269,11 @@ __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
         stage_weights_t<D>(Ws, theta + (long)layer * lsz, 4, use_ln ? 2 * D : 0);
         __syncthreads();
         float a[D], on[D], mx[NH], ls[NH];
-        mhsa_layer_fwd<D, NH>(a, on, mx, ls, Xs, Ks, Vs, Ws, S, live, use_ln, use_res);
+        unsigned rk[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) rk[h] = DROP ? drop_row_key(*drop.seed, b, layer, n_layers, h, NH, s) : 0u;
+        mhsa_layer_fwd<D, NH, DROP>(a, on, mx, ls, Xs, Ks, Vs, Ws, S, live, use_ln, use_res, rk, drop.thresh,
+                                    drop.keep_scale);
         if (live) {
             // saved for backward: the layer's output tokens, its attention output (before W_o) and the
             // softmax statistics (max, 1/sum) of every query row
@@ -305,15 +334,18 @@ static size_t attn_fwd_lds(int S, int D) {
 template <int D, int NH>
 static int launch_attn_fwd(const float* fm, int B, int S, int n_layers, int use_ln, int use_res,
                            const float* theta, float* out, float* tok_save, float* o_save, float* ml_save,
-                           hipStream_t st) {
+                           AttnDrop drop, hipStream_t st) {
     const int threads = (int)round_up(S, 64);
     const size_t lds = attn_fwd_lds(S, D);
-    if (threads <= 512)
-        hipLaunchKernelGGL((attn_pool_fwd_kernel<D, NH, 512>), dim3(B), dim3(threads), lds, st, fm, (long)B * D, B, S,
-                           n_layers, use_ln, use_res, theta, out, tok_save, o_save, ml_save);
-    else
-        hipLaunchKernelGGL((attn_pool_fwd_kernel<D, NH, 1024>), dim3(B), dim3(threads), lds, st, fm, (long)B * D, B, S,
-                           n_layers, use_ln, use_res, theta, out, tok_save, o_save, ml_save);
+#define XDFM_ATTN_FWD(TB, DR)                                                                                       \
+    hipLaunchKernelGGL((attn_pool_fwd_kernel<D, NH, TB, DR>), dim3(B), dim3(threads), lds, st, fm, (long)B * D, B, S, \
+                       n_layers, use_ln, use_res, theta, out, tok_save, o_save, ml_save, drop)
+    if (drop.seed) {
+        if (threads <= 512) XDFM_ATTN_FWD(512, true); else XDFM_ATTN_FWD(1024, true);
+    } else {
+        if (threads <= 512) XDFM_ATTN_FWD(512, false); else XDFM_ATTN_FWD(1024, false);
+    }
+#undef XDFM_ATTN_FWD
     return xdfm_check_launch("cin_attn_pool_fwd");
 }
 
@@ -386,7 +418,7 @@ static __host__ __device__ inline AttnBwdLds attn_bwd_layout(int S, int D, int N
     int off = 0;
     L.kv = off;  off += 2 * S * D;                   // K,V  then Q,dO
     L.z = off;   off += TP * (D + 1);                // the one per-thread tile: dy / du / dq / dk / dv rows
-    L.st = off;  off += S * 3 * NH;                  // per query: max, 1/sum, delta  per head
+    L.st = off;  off += S * 4 * NH;                  // per query: max, 1/sum, delta, dropout row key  per head
     L.w = off;   off += 8 * D * D + 2 * D;           // transposed + plain weights of the stage
     L.acc = off; off += n_layers * (4 * D * D + 2 * D) + D * D + 2 * D;   // parameter-gradient accumulator
     L.red = off; off += 16 + 16 * D;
@@ -394,12 +426,12 @@ static __host__ __device__ inline AttnBwdLds attn_bwd_layout(int S, int D, int N
     return L;
 }
 
-template <int D, int NH, int TB>
+template <int D, int NH, int TB, bool DROP>
 __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
     const float* __restrict__ fm, long N, int B, int S, int n_layers, int use_ln, int use_res,
     const float* __restrict__ theta, const float* __restrict__ tok_save, const float* __restrict__ o_save,
     const float* __restrict__ ml_save, const float* __restrict__ dout, float* __restrict__ dfm,
-    float* __restrict__ dtheta) {
+    float* __restrict__ dtheta, AttnDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = D / NH;
     constexpr int XP = D + 1;
@@ -565,7 +597,11 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                 for (int e = 0; e < HD; ++e) a = fmaf(dO[h * HD + e], o[h * HD + e], a);
                 delta[h] = a;
             }
-            // pass A (thread = query): dq
+            // pass A (thread = query): dq.  Under dropout P' = P.M/(1-p): dP = M/(1-p) . (dO V^T), and
+            // delta = sum_t P dP = dO . o still holds because o was built from P'.
+            unsigned rk[NH];
+#pragma unroll
+            for (int h = 0; h < NH; ++h) rk[h] = DROP ? drop_row_key(*drop.seed, b, layer, n_layers, h, NH, s) : 0u;
             float dq[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) dq[d] = 0.f;
@@ -581,6 +617,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                     float dp = 0.f;
 #pragma unroll
                     for (int e = 0; e < HD; ++e) dp = fmaf(dO[h * HD + e], v[h * HD + e], dp);
+                    if (DROP) dp *= drop_keep(rk[h], t, drop.thresh, drop.keep_scale);
                     const float ds = p * (dp - delta[h]) * scale;
 #pragma unroll
                     for (int e = 0; e < HD; ++e) dq[h * HD + e] = fmaf(ds, k[h * HD + e], dq[h * HD + e]);
@@ -595,9 +632,10 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                 store_row<D>(dOs + s * D, dO);
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    St[(s * NH + h) * 3] = mx[h];
-                    St[(s * NH + h) * 3 + 1] = il[h];
-                    St[(s * NH + h) * 3 + 2] = delta[h];
+                    St[(s * NH + h) * 4] = mx[h];
+                    St[(s * NH + h) * 4 + 1] = il[h];
+                    St[(s * NH + h) * 4 + 2] = delta[h];
+                    St[(s * NH + h) * 4 + 3] = __uint_as_float(rk[h]);
                 }
             }
 #pragma unroll
@@ -617,14 +655,18 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                 head_scores<D, NH>(qs, kk, scale, sc);
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    const float p = __expf(sc[h] - St[(r * NH + h) * 3]) * St[(r * NH + h) * 3 + 1];
+                    const float4 stq = *reinterpret_cast<const float4*>(St + (r * NH + h) * 4);
+                    const float p = __expf(sc[h] - stq.x) * stq.y;
+                    const float keep = DROP ? drop_keep(__float_as_uint(stq.w), s, drop.thresh, drop.keep_scale) : 1.f;
                     float dp = 0.f;
 #pragma unroll
                     for (int e = 0; e < HD; ++e) dp = fmaf(dos[h * HD + e], vv[h * HD + e], dp);
-                    const float ds = p * (dp - St[(r * NH + h) * 3 + 2]) * scale;
+                    if (DROP) dp *= keep;
+                    const float ds = p * (dp - stq.z) * scale;
+                    const float pv = DROP ? p * keep : p;
 #pragma unroll
                     for (int e = 0; e < HD; ++e) {
-                        dv[h * HD + e] = fmaf(p, dos[h * HD + e], dv[h * HD + e]);
+                        dv[h * HD + e] = fmaf(pv, dos[h * HD + e], dv[h * HD + e]);
                         dk[h * HD + e] = fmaf(ds, qs[h * HD + e], dk[h * HD + e]);
                     }
                 }
@@ -664,18 +706,47 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
 template <int D, int NH>
 static int launch_attn_bwd(const float* fm, int B, int S, int n_layers, int use_ln, int use_res, const float* theta,
                            const float* tok_save, const float* o_save, const float* ml_save, const float* dout,
-                           float* dfm, float* dtheta, hipStream_t st) {
+                           float* dfm, float* dtheta, AttnDrop drop, hipStream_t st) {
     const int threads = (int)round_up(S, 64);
     const size_t lds = (size_t)attn_bwd_layout(S, D, NH, n_layers, threads).total * sizeof(float);
     if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_attn_pool_bwd: S=%d D=%d does not fit LDS", S, D);
     const int grid = B < 2048 ? B : 2048;
-    if (threads <= 512)
-        hipLaunchKernelGGL((attn_pool_bwd_kernel<D, NH, 512>), dim3(grid), dim3(threads), lds, st, fm, (long)B * D, B, S,
-                           n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta);
-    else
-        hipLaunchKernelGGL((attn_pool_bwd_kernel<D, NH, 1024>), dim3(grid), dim3(threads), lds, st, fm, (long)B * D, B, S,
-                           n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta);
+#define XDFM_ATTN_BWD(TB, DR)                                                                                          \
+    hipLaunchKernelGGL((attn_pool_bwd_kernel<D, NH, TB, DR>), dim3(grid), dim3(threads), lds, st, fm, (long)B * D, B, S, \
+                       n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta, drop)
+    if (drop.seed) {
+        if (threads <= 512) XDFM_ATTN_BWD(512, true); else XDFM_ATTN_BWD(1024, true);
+    } else {
+        if (threads <= 512) XDFM_ATTN_BWD(512, false); else XDFM_ATTN_BWD(1024, false);
+    }
+#undef XDFM_ATTN_BWD
     return xdfm_check_launch("cin_attn_pool_bwd");
+}
+
+// The keep mask the kernels above regenerate, written out: keep[layer][b][h][q][t] (1 = kept).  Test hook -- the
+// parity tests feed it to the oracle, which applies it where the reference applies nn.Dropout.
+__global__ void attn_dropout_mask_kernel(int B, int S, int nh, int n_layers, AttnDrop drop, unsigned char* keep) {
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (layer, b, h, q)
+    if (row >= (long)n_layers * B * nh * S) return;
+    const int q = (int)(row % S);
+    long r = row / S;
+    const int h = (int)(r % nh); r /= nh;
+    const int b = (int)(r % B);
+    const int layer = (int)(r / B);
+    const unsigned rk = drop_row_key(*drop.seed, b, layer, n_layers, h, nh, q);
+    for (int t = 0; t < S; ++t) keep[row * S + t] = drop_keep(rk, t, drop.thresh, 1.f) != 0.f;
+}
+
+static int attn_drop_args(float p_drop, const unsigned long long* seed, AttnDrop* d, const char* who) {
+    d->seed = nullptr; d->thresh = 0; d->keep_scale = 1.f;
+    if (!(p_drop >= 0.f && p_drop < 1.f)) return xdfm_fail(XDFM_ERR_INVALID, "%s: dropout p=%g outside [0, 1)", who, p_drop);
+    if (p_drop == 0.f) return 0;
+    if (!seed) return xdfm_fail(XDFM_ERR_INVALID, "%s: dropout p=%g needs a device seed", who, p_drop);
+    d->seed = seed;
+    const double t = (double)p_drop * 4294967296.0;
+    d->thresh = t >= 4294967295.0 ? 4294967295u : (unsigned)t;
+    d->keep_scale = 1.0f / (1.0f - p_drop);
+    return 0;
 }
 
 extern "C" {
@@ -686,25 +757,43 @@ size_t xdfm_cin_attn_theta_elems(int D, int n_layers, int use_ln) {
 
 int xdfm_cin_attn_pool_fwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
                            const float* theta, float* out, float* tok_save, float* o_save, float* ml_save,
-                           void* stream) {
+                           float p_drop, const unsigned long long* drop_seed, void* stream) {
     XDFM_REQUIRE(fm && theta && out && ml_save && tok_save && o_save, "cin_attn_pool_fwd: null pointer");
     XDFM_REQUIRE(B > 0 && S > 0 && S <= 1024 && n_layers >= 1, "cin_attn_pool_fwd: bad shape B=%d S=%d layers=%d", B, S,
                  n_layers);
     XDFM_REQUIRE(attn_fwd_lds(S, D) <= 160 * 1024, "cin_attn_pool_fwd: S=%d D=%d does not fit LDS", S, D);
+    AttnDrop drop;
+    if (int rc = attn_drop_args(p_drop, drop_seed, &drop, "cin_attn_pool_fwd")) return rc;
     hipStream_t st = (hipStream_t)stream;
-    ATTN_DISPATCH(launch_attn_fwd, fm, B, S, n_layers, use_ln, use_res, theta, out, tok_save, o_save, ml_save, st)
+    ATTN_DISPATCH(launch_attn_fwd, fm, B, S, n_layers, use_ln, use_res, theta, out, tok_save, o_save, ml_save, drop, st)
 }
 
 int xdfm_cin_attn_pool_bwd(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
                            const float* theta, const float* tok_save, const float* o_save, const float* ml_save,
-                           const float* dout, float* dfm, float* dtheta, void* stream) {
+                           const float* dout, float* dfm, float* dtheta, float p_drop,
+                           const unsigned long long* drop_seed, void* stream) {
     XDFM_REQUIRE(fm && theta && tok_save && o_save && ml_save && dout && dfm && dtheta,
                  "cin_attn_pool_bwd: null pointer");
     XDFM_REQUIRE(B > 0 && S > 0 && S <= 1024 && n_layers >= 1, "cin_attn_pool_bwd: bad shape B=%d S=%d layers=%d", B, S,
                  n_layers);
+    AttnDrop drop;
+    if (int rc = attn_drop_args(p_drop, drop_seed, &drop, "cin_attn_pool_bwd")) return rc;
     hipStream_t st = (hipStream_t)stream;
     ATTN_DISPATCH(launch_attn_bwd, fm, B, S, n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta,
-                  st)
+                  drop, st)
+}
+
+int xdfm_cin_attn_dropout_mask(int B, int S, int nh, int n_layers, float p_drop, const unsigned long long* drop_seed,
+                               unsigned char* keep, void* stream) {
+    XDFM_REQUIRE(keep && drop_seed, "cin_attn_dropout_mask: null pointer");
+    XDFM_REQUIRE(B > 0 && S > 0 && nh > 0 && n_layers > 0, "cin_attn_dropout_mask: bad shape");
+    AttnDrop drop;
+    if (int rc = attn_drop_args(p_drop, drop_seed, &drop, "cin_attn_dropout_mask")) return rc;
+    XDFM_REQUIRE(drop.seed, "cin_attn_dropout_mask: p_drop must be > 0");
+    const long rows = (long)n_layers * B * nh * S;
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       B, S, nh, n_layers, drop, keep);
+    return xdfm_check_launch("cin_attn_dropout_mask");
 }
 
 }  // extern "C"

@@ -5,7 +5,7 @@ import of any op fails with an explicit error, and every op refuses non-CUDA ten
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_long, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
 
 # torch must be imported BEFORE the library is dlopen'ed: the torch wheel bundles its own
 # libamdhip64 and the process must end up with ONE HIP runtime (the one that owns torch's device
@@ -43,8 +43,10 @@ SIGNATURES = {
     "xdfm_cin_bwd_w_ws_elems": (c_size_t, [c_int, c_int, c_int, c_long]),
     "xdfm_cin_level_bwd_w": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
-    "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P]),
-    "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P]),
+    "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_float,
+                                       P, P]),
+    "xdfm_cin_attn_dropout_mask": (c_int, [c_int, c_int, c_int, c_int, c_float, P, P, P]),
     "xdfm_head_ws_elems": (c_size_t, [c_int, c_int]),
     "xdfm_head_fwd": (c_int, [P, P, P, c_int, P, P, c_int, P, P, c_int, P, P, P, P]),
     "xdfm_head_bwd": (c_int, [P, P, P, P, P, c_int, P, P, c_int, c_int, P, P, P, P, P, P]),
@@ -69,7 +71,7 @@ class AdamTensor(ctypes.Structure):
                 ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float), ("grad_marks", c_void_p), ("flags", c_int)]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _lib = None
 
 

@@ -482,10 +482,13 @@ def from_fm_layout(t: torch.Tensor, B: int, D: int) -> torch.Tensor:
 class AttnPool(torch.autograd.Function):
     """FM-layout feature maps [S, B*D] -> pooled [B, D] through n_layers x (MHSA, +residual, LayerNorm)
     and the attention pooling (deepctr/layers/cin_attention.py:63-144, :302-313, :452-464).
-    params: per layer Wq, Wk, Wv, Wo (+ gamma, beta when use_ln), then W1, b1, w2."""
+    params: per layer Wq, Wk, Wv, Wo (+ gamma, beta when use_ln), then W1, b1, w2.
+    p_drop > 0: attention dropout (cin_attention.py:86); the seed of the keep mask is drawn on the device from
+    torch's generator (torch.manual_seed makes a run repeatable, a captured graph draws a new one per replay)
+    and kept for backward, which regenerates the mask instead of storing it."""
 
     @staticmethod
-    def forward(ctx, fm, B, D, nh, n_layers, use_ln, use_res, *params):
+    def forward(ctx, fm, B, D, nh, n_layers, use_ln, use_res, p_drop, *params):
         _need_cuda(fm, "feature maps")
         lib = _lib.load()
         S = fm.shape[0]
@@ -499,10 +502,14 @@ class AttnPool(torch.autograd.Function):
         ml = torch.empty((n_layers, B, S, nh, 2), dtype=torch.float32, device=dev)
         # S^2 * (3 D FMA) per example and layer, counted as 2 FLOP per FMA
         flops = 2.0 * 3 * D * S * S * B * n_layers
+        p_drop = float(p_drop)
+        seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64, device=dev) if p_drop > 0 else None
         _lib.check(_run("cin_attn_pool_fwd", flops, lambda: lib.xdfm_cin_attn_pool_fwd(
             _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(out), _ptr(tok), _ptr(osv),
-            _ptr(ml), _stream())), "cin_attn_pool_fwd")
-        ctx.cfg = (B, D, nh, n_layers, use_ln, use_res, [tuple(p.shape) for p in params])
+            _ptr(ml), p_drop, _ptr(seed) if seed is not None else None, _stream())), "cin_attn_pool_fwd")
+        ctx.cfg = (B, D, nh, n_layers, use_ln, use_res, p_drop, [tuple(p.shape) for p in params])
+        ctx.drop_seed = seed
+        AttnPool.last_drop_seed = seed          # read by the parity tests (xdfm_cin_attn_dropout_mask)
         ctx.save_for_backward(fm, theta, tok, osv, ml)
         return out
 
@@ -510,7 +517,8 @@ class AttnPool(torch.autograd.Function):
     def backward(ctx, dout):
         lib = _lib.load()
         fm, theta, tok, osv, ml = ctx.saved_tensors
-        B, D, nh, n_layers, use_ln, use_res, shapes = ctx.cfg
+        B, D, nh, n_layers, use_ln, use_res, p_drop, shapes = ctx.cfg
+        seed = ctx.drop_seed
         S = fm.shape[0]
         dfm = torch.empty_like(fm)
         dtheta = torch.zeros_like(theta)
@@ -518,7 +526,8 @@ class AttnPool(torch.autograd.Function):
         flops = 2.0 * 7 * D * S * S * B * n_layers
         _lib.check(_run("cin_attn_pool_bwd", flops, lambda: lib.xdfm_cin_attn_pool_bwd(
             _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(tok), _ptr(osv), _ptr(ml),
-            _ptr(dout), _ptr(dfm), _ptr(dtheta), _stream())), "cin_attn_pool_bwd")
+            _ptr(dout), _ptr(dfm), _ptr(dtheta), p_drop, _ptr(seed) if seed is not None else None, _stream())),
+            "cin_attn_pool_bwd")
         grads, off = [], 0
         for sh in shapes:
             n = 1
@@ -526,7 +535,7 @@ class AttnPool(torch.autograd.Function):
                 n *= k
             grads.append(dtheta[off:off + n].view(sh))
             off += n
-        return (dfm, None, None, None, None, None, None) + tuple(grads)
+        return (dfm, None, None, None, None, None, None, None) + tuple(grads)
 
 
 def attn_pool(fm, B, D, mhsa_layers, layer_norms, pooling, use_res):
@@ -538,12 +547,15 @@ def attn_pool(fm, B, D, mhsa_layers, layer_norms, pooling, use_res):
         params += [att.W_q.weight, att.W_k.weight, att.W_v.weight, att.W_o.weight]
         if layer_norms is not None:
             params += [layer_norms[l].weight, layer_norms[l].bias]
-        if att.dropout.p > 0 and att.training:
-            raise NotImplementedError("attention dropout > 0 is not implemented in the fused kernel "
-                                      "(the reference's scripts train with cin_attn_dropout = 0)")
     params += [pooling.attention[0].weight, pooling.attention[0].bias, pooling.attention[2].weight]
     nh = mhsa_layers[0].num_heads
-    return AttnPool.apply(fm, B, D, nh, len(mhsa_layers), layer_norms is not None, bool(use_res), *params)
+    att0 = mhsa_layers[0]
+    p_drop = float(att0.dropout.p) if att0.training else 0.0      # every layer is built with the same attn_dropout
+    if any(float(a.dropout.p) != float(att0.dropout.p) for a in mhsa_layers):
+        raise ValueError("cin_attn_pool: the attention layers must share one dropout rate")
+    if p_drop >= 1.0:
+        raise ValueError("cin_attn_pool: attention dropout must be < 1, got %g" % p_drop)
+    return AttnPool.apply(fm, B, D, nh, len(mhsa_layers), layer_norms is not None, bool(use_res), p_drop, *params)
 
 
 # --------------------------------------------------------------------------------------------- #
