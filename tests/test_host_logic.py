@@ -195,3 +195,39 @@ def test_entry_point_reader_and_preprocessor(tmp_path):
     assert x["C1"].tolist() == [1, 2, 1] and x["C2"].tolist() == [1, 2, 0]      # "a0" unseen for C2 -> 0
     assert prep.vocab("C1") == 3 and x["I2"].dtype == np.float32
     assert x["I2"][0] == 0.0 and x["I2"][1] == 1.0 and abs(x["I2"][2] - 5.0) < 1e-6   # (6 - 1) / (2 - 1): scaled with the fit range
+
+
+def test_entry_point_flags_follow_the_three_reference_scripts():
+    """xdftrain_amd.py accepts the command lines of xdftrain.py / xdftrain_attn.py / xdftrain_pro.py (run.bash,
+    run_attn.bash, run_sfg.bash flows): --mode eval|final, --cin_attn_dropout, the SFG / AutoDis flags, --stratify,
+    and each script's own defaults for epochs / batch sizes / out_dir (xdftrain.py:725-727, xdftrain_attn.py:747-749,
+    xdftrain_pro.py:795-797)."""
+    import importlib.util
+    import os
+    from conftest import PKG
+    spec = importlib.util.spec_from_file_location("xdftrain_amd", os.path.join(PKG, "xdftrain_amd.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a = mod.parse_args(["--data_path", "x.txt"])
+    assert (a.mode, a.model, a.epochs, a.batch_size, a.pred_batch_size, a.out_dir) == \
+        ("eval", "xdeepfm", 3, 4096, 8192, "./outputs_xdeepfm")
+    a = mod.parse_args(["--data_path", "x.txt", "--mode", "final", "--model_version", "v2", "--cin_attn_dropout", "0.1",
+                        "--cin_no_residual", "--cin_num_attn_layers", "2", "--stratify"], model="attn")
+    assert (a.mode, a.model, a.epochs, a.cin_attn_dropout, a.cin_use_residual, a.cin_use_layer_norm, a.stratify) == \
+        ("final", "attn", 50, 0.1, False, True, True)
+    a = mod.parse_args(["--data_path", "x.txt", "--sfg_hidden_units", "64", "32", "--sfg_all_samples", "--use_autodis",
+                        "--autodis_buckets", "8", "--use_light_version", "--epochs", "5"], model="pro")
+    assert (a.model, a.epochs, a.batch_size, a.pred_batch_size, a.sfg_hidden_units, a.sfg_positive_only, a.use_sfg,
+            a.use_autodis, a.autodis_buckets, a.use_light_version, a.out_dir) == \
+        ("pro", 5, 2048, 4096, [64, 32], False, True, True, 8, True, "./outputs_xdeepfm_pro")
+    assert mod.parse_args(["--no_sfg"], model="pro").use_sfg is False
+    for shim in ("xdftrain.py", "xdftrain_attn.py", "xdftrain_pro.py"):
+        assert os.path.exists(os.path.join(PKG, shim))
+    # split: plain and stratified (class ratio kept in both parts, nothing lost, nothing shared)
+    y = (np.arange(1000) % 10 == 0).astype(np.float64)
+    for strat in (False, True):
+        tr, va = mod.split_rows(y, 0.2, 7, strat)
+        assert len(va) == 200 and sorted(np.concatenate([tr, va]).tolist()) == list(range(1000))
+    assert y[va].sum() == 20 and y[tr].sum() == 80
+    tr2, va2 = mod.split_rows(y, 0.2, 7, True)
+    assert np.array_equal(tr, tr2) and np.array_equal(va, va2)

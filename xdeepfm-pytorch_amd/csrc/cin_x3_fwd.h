@@ -1,0 +1,316 @@
+// Forward kernel of the f16x3 / bf16 CIN arithmetic (see cin_x3.hip) as a header: the instances for the
+// BASELINE field counts (m = 22, 26) are compiled in cin_x3.hip, those for every other even m <= 40 in
+// cin_x3_fwd_ma.hip / cin_x3_fwd_mb.hip (two more translation units, so the build stays parallel).
+#pragma once
+#include <type_traits>
+#include "xdfm_internal.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));      // 16 bytes of MFMA operand (fp16 halves, or bf16 bit patterns)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values -> two bf16 (RNE, v_cvt_pk_bf16_f32) carried as the bit patterns of an h2
+__device__ __forceinline__ h2 x3_bf16_pair(float a, float b) {
+    const f2 z = {a, b};
+    return __builtin_bit_cast(h2, __builtin_convertvector(z, bf2));
+}
+// one MFMA term: NT == 3 -> fp16 operands, NT == 1 -> the same 16 bytes read as bf16
+template <int NT>
+__device__ __forceinline__ f32x16 x3_mfma(const h8& a, const h8& b, const f32x16& c) {
+    if constexpr (NT == 3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
+}
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// power of two s with amax*s in [2^(target-1), 2^target); 1 for amax == 0 or denormal
+__device__ __forceinline__ float x3_pow2_scale(float amax, int target) {
+    const int E = (int)((__float_as_uint(amax) >> 23) & 0xff);
+    int be = 253 + target - E;
+    be = be < 1 ? 1 : (be > 253 ? 253 : be);
+    return E == 0 ? 1.f : __uint_as_float((unsigned)be << 23);
+}
+
+__device__ __forceinline__ void x3_split2(float z0, float z1, h2& hi, h2& lo) {
+    const f2 z = {z0, z1};
+    hi = __builtin_convertvector(z, h2);                 // v_cvt_pk_f16_f32 (RNE)
+    const f2 r = {z0 - (float)hi.x, z1 - (float)hi.y};   // exact in fp32
+    lo = __builtin_convertvector(r, h2);
+}
+
+// hi / lo halves of the two products a0*b0, a1*b1: one v_pk_mul_f32 + v_cvt_pk_f16_f32 for hi, then
+// lo = rne16(a*b - hi) with the exact product inside one v_fma_mix_f32 per element (its third operand is the
+// fp16 half, read in place) -- 5 VALU instructions per pair.
+__device__ __forceinline__ void x3_split_prod2(float a0, float b0, float a1, float b1, h2& hi, h2& lo) {
+    const f2 z = (f2){a0, a1} * (f2){b0, b1};
+    hi = __builtin_convertvector(z, h2);
+    const unsigned hbits = __builtin_bit_cast(unsigned, hi);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(a0), "v"(b0), "v"(hbits));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(a1), "v"(b1), "v"(hbits));
+    const f2 r = {r0, r1};
+    lo = __builtin_convertvector(r, h2);
+}
+
+// max_i |col[i * N]| over rows i = first, first + 2, ... < rows: 16 unconditional loads in flight per round trip
+// (rows past the end are clamped to a row of the set: harmless for a maximum; more in flight costs the MT = 8
+// kernels registers they do not have).  A loop with a few loads per iteration pays an L2 round trip per iteration.
+__device__ __forceinline__ float x3_col_absmax(const float* __restrict__ col, long N, int first, int rows) {
+    float mx = 0.f;
+    for (int i0 = first; i0 < rows; i0 += 32) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = i0 + 2 * k;
+            v[k] = col[(long)(i < rows ? i : first) * N];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mx = fmaxf(mx, fabsf(v[k]));
+    }
+    return first < rows ? mx : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Forward kernel.  Workgroup = 4 waves = 128 columns x (32*MT rows of one row group mb); a wave owns
+// 32 columns and all MT row tiles.  The packed weight fragments of one step (2*MT KB) are shared by the
+// four waves through a 3-deep LDS ring filled by 16-byte LDS-DMA two steps ahead (one counted
+// s_waitcnt vmcnt + raw s_barrier per step); each wave builds its own B operand (Z hi / lo) in registers.
+// NT = MFMA terms per product: 3 (f16x3: hi / lo fp16 halves, range-fitted) or 1 (bf16 operands, no scales)
+template <int MT, int M, int NW, int R = 3, int NT = 3>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
+    const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ pack,
+    const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MP = M / 2;
+    constexpr int FRT = NT == 3 ? 2 : 1;        // 1-KB fragments per row tile (hi, lo | bf16)
+    constexpr int FR = FRT * MT;                // 1-KB fragments per stage
+    constexpr int STAGE = FR * 1024;            // bytes
+    constexpr int FPW = FR / NW;                // LDS-DMA instructions per wave and stage
+    static_assert(FR % NW == 0, "every wave issues the same number of LDS-DMA pieces");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const long n = ((long)blockIdx.x * NW + wave) * 32 + c;
+    const bool nok = n < N;                     // no early exit: every wave feeds the ring and the barriers
+    const long nc = nok ? n : N - 1;
+    const float nmask = nok ? 1.f : 0.f;
+    const int mb = blockIdx.y;
+    const int dbg = act >> 8;                   // timing experiments (xdfm option "dbg" bits 6..11): 1 no stores, 2 one block, 8 no operand work, 16 no weight DMA
+    act &= 0xff;
+
+    const char* wsrc = reinterpret_cast<const char*>(pack + X3_HDR) + (long)mb * (G.NS + 2) * STAGE + lane * 16;
+    auto dma_stage = [&](const char* src, int slot_off) {
+#pragma unroll
+        for (int k = 0; k < FPW; ++k) {
+            const int f = wave * FPW + k;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + f * 1024),
+                                             (LDS_AS void*)(smem + slot_off + f * 1024), 16, 0, 0);
+        }
+    };
+    // x_prev rows of a block (8 rows x the workgroup's 32*NW columns) also arrive by LDS-DMA, one block ahead, into
+    // two buffers behind the ring: per-lane global loads of them made hipcc drain the whole VMEM queue (s_waitcnt
+    // vmcnt(0)) at every block boundary -- the ring's look-ahead with it -- and cost 4 dependent round trips in the
+    // prologue.  4-byte pieces: no alignment requirement on N or xp.
+    constexpr int XCOLS = 32 * NW;              // columns of the workgroup
+    constexpr int XPI = 8 * XCOLS / 64 / NW;    // x_prev DMA instructions per wave and block (256 B each)
+    float* xbuf = reinterpret_cast<float*>(smem + R * STAGE);           // [2][8][XCOLS]
+    float* bias_s = xbuf + 2 * 8 * XCOLS;                               // [32 * MT] bias of the workgroup's rows
+    if ((int)threadIdx.x < 32 * MT) {
+        const int row = blockIdx.y * MT * 32 + threadIdx.x;
+        bias_s[threadIdx.x] = bias[row < H ? row : H - 1];
+    }
+    const long col0 = (long)blockIdx.x * XCOLS;
+    auto dma_xp = [&](int blk, int buf) {
+#pragma unroll
+        for (int k = 0; k < XPI; ++k) {
+            const int e = (wave * XPI + k) * 64;                        // first element of this piece in the [8][XCOLS] tile
+            const int row = e / XCOLS;                                  // wave-uniform
+            int i = blk * 8 + row;
+            i = i < Hp ? i : Hp - 1;                                    // rows past the matrix: any valid row (their factor is 0)
+            long col = col0 + (e - row * XCOLS) + lane;
+            col = col < N ? col : N - 1;
+            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xp + (long)i * N + col),
+                                             (LDS_AS void*)(xbuf + buf * 8 * XCOLS + e), 4, 0, 0);
+        }
+    };
+    dma_xp(0, 0);
+    // the ring runs R - 1 stages ahead of the step being read (R slots); the packed stream ends with 2 spare stages
+    const char* wlast = wsrc + (long)(G.NS + 1) * STAGE;      // last stage that exists (reads past it are clamped to it)
+#pragma unroll
+    for (int k = 0; k < R - 1; ++k) dma_stage(wsrc + (long)(k < G.NS + 2 ? k : G.NS + 1) * STAGE, k * STAGE);
+
+    // ---- x0 column (registers), column scales --------------------------------------------------
+    float x0r[M];
+    float a0 = 0.f;
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        x0r[j] = x0[(long)j * N + nc] * nmask;
+        a0 = fmaxf(a0, fabsf(x0r[j]));
+    }
+    float ap = 0.f;
+    if (NT != 3) {
+    } else if (xp == x0) {
+        ap = a0;
+    } else {
+        ap = x3_col_absmax(xp + nc, N, hh, Hp);
+        ap = fmaxf(ap, __shfl_xor(ap, 32)) * nmask;
+    }
+    // bf16 operands need no range fitting
+    const float s0 = NT == 3 ? x3_pow2_scale(a0, 7) : 1.f, sp = NT == 3 ? x3_pow2_scale(ap, 7) : 1.f;
+#pragma unroll
+    for (int j = 0; j < M; ++j) x0r[j] *= s0;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // x_prev rows of this lane half in block blk: blk*8 + hh*RH + il, read from the block's LDS buffer and multiplied
+    // by their factor (column scale, or 0 for rows / columns outside the matrix)
+    auto read_xp = [&](int blk, int RH, float (&v)[4]) {
+        const float* xb = xbuf + (blk & 1) * 8 * XCOLS + wave * 32 + c;
+#pragma unroll
+        for (int il = 0; il < 4; ++il) {
+            const int i = blk * 8 + hh * RH + il;
+            const bool ok = il < RH && i < Hp;
+            v[il] = xb[(ok ? hh * RH + il : 0) * XCOLS] * (ok ? sp * nmask : 0.f);
+        }
+    };
+    // B operand (hi, lo) of step s of a block from the block's 4 x_prev values
+    auto build_b = [&](int s, const float (&xv)[4], h8& bh, h8& bl) {
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            const int q = 8 * s + 2 * t2, il = q / M, j = q - il * M;
+            h2 hi = h2{0, 0}, lo = h2{0, 0};
+            if (il < 4) {
+                if constexpr (NT == 3) x3_split_prod2(xv[il], x0r[j], xv[il], x0r[j + 1], hi, lo);
+                else hi = x3_bf16_pair(xv[il] * x0r[j], xv[il] * x0r[j + 1]);
+            }
+            bh[2 * t2] = hi.x; bh[2 * t2 + 1] = hi.y;
+            bl[2 * t2] = lo.x; bl[2 * t2 + 1] = lo.y;
+        }
+    };
+
+    int so[R];                                  // LDS offsets of the ring slots of steps s % R of this block
+#pragma unroll
+    for (int q = 0; q < R; ++q) so[q] = q * STAGE;
+    const int nblk = G.FB + (G.TS > 0 ? 1 : 0);
+    float xv[4], xn[4];
+    // block 0's rows have landed (they were issued before the ring's first stages) for every wave
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * FPW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    read_xp(0, G.FB > 0 ? 4 : G.RH, xv);
+    h8 bh, bl;
+    build_b(0, xv, bh, bl);
+    const char* wblk = wsrc;
+    auto block_steps = [&](int blk, int nsteps_dyn, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const bool has_next = blk + 1 < nblk;
+#pragma unroll
+        for (int s = 0; s < MP; ++s) {
+            if (FULL || s < nsteps_dyn) {       // wave-uniform
+            h8 nh = bh, nl = bl;                         // operand of the step after this one, built in its shadow
+            if (dbg & 8) {
+            } else if (s + 1 < MP) {
+                if (FULL || s + 1 < nsteps_dyn) build_b(s + 1, xv, nh, nl);
+            } else if (has_next) {
+                read_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn);       // landed and published since step R - 1 of this block
+                build_b(0, xn, nh, nl);
+            }
+            // stage (blk, s) has landed for this wave's pieces; after the barrier for everyone's.  Younger than its
+            // DMA: the R - 2 stages after it, and in steps 1 .. R-2 of a block the next block's x_prev pieces (issued
+            // in step 0 right after the barrier, before that step's stage)
+            constexpr int AHEAD = R - 2;
+            if (has_next && s >= 1 && s <= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * FPW + XPI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * FPW) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (s == 0 && has_next) dma_xp(blk + 1, (blk + 1) & 1);
+            {
+                const char* src = wblk + (long)(s + R - 1) * STAGE;
+                if (!(dbg & 16)) dma_stage(src < wlast ? src : wlast, so[(s + R - 1) % R]);
+            }
+            const char* st = smem + so[s % R] + lane * 16;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const h8 ah = *reinterpret_cast<const h8*>(st + (FRT * mt) * 1024);
+                acc[mt] = x3_mfma<NT>(ah, bh, acc[mt]);
+                if constexpr (NT == 3) {
+                    const h8 al = *reinterpret_cast<const h8*>(st + (2 * mt + 1) * 1024);
+                    acc[mt] = x3_mfma<NT>(ah, bl, acc[mt]);
+                    acc[mt] = x3_mfma<NT>(al, bh, acc[mt]);
+                }
+            }
+            bh = nh; bl = nl;
+            }
+        }
+        // next block: rotate the ring slots by the number of steps taken, first B operand
+        const int adv = FULL ? MP : nsteps_dyn;
+        wblk += (long)adv * STAGE;
+        for (int k = 0; k < adv % R; ++k) {
+#pragma unroll
+            for (int q = 0; q + 1 < R; ++q) { const int t = so[q]; so[q] = so[q + 1]; so[q + 1] = t; }
+        }
+        if (has_next) {
+#pragma unroll
+            for (int il = 0; il < 4; ++il) xv[il] = xn[il];
+        }
+    };
+    for (int blk = 0; blk < ((dbg & 2) ? 1 : G.FB); ++blk) block_steps(blk, MP, std::true_type{});
+    if (G.TS > 0) block_steps(G.FB, G.TS, std::false_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two look-ahead stages must land before LDS is released
+
+    // ---- epilogue: remove the scales, bias + activation, FM-layout store --------------------------
+    // The bias values of the workgroup's rows sit in LDS since the prologue: their reads count on lgkmcnt, so nothing
+    // makes hipcc put an s_waitcnt vmcnt(0) -- which also waits for the previous STORE -- in front of every store
+    // (with per-row global loads of the bias it did: 16 write round trips per row tile).
+    const float sc = NT == 3 ? pack[1] * (1.f / sp) * (1.f / s0) : 1.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        __builtin_amdgcn_sched_barrier(0);          // one row tile at a time: 16 store addresses live, not 16 * MT
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (mb * MT + mt) * 32 + frag_row(r, hh);
+            float v = acc[mt][r] * sc + bias_s[mt * 32 + frag_row(r, hh)];
+            if (act == XDFM_ACT_RELU) v = fmaxf(v, 0.f);
+            if (row < H && nok && (!(dbg & 1) || acc[mt][r] == 12345.f)) out[(long)row * N + n] = v;
+        }
+    }
+}
+
+// NW waves (= 32*NW columns) share one weight ring: 8 waves halve the L2 -> LDS traffic of the ring (every
+// workgroup streams the whole packed matrix: 512 x 1.7 MB per launch at config 2 with 4 waves)
+template <int MT, int M, int NT>
+static int launch_x3(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, long N,
+                     const X3Geom& g, int act, float* out, hipStream_t st) {
+    constexpr int FR = (NT == 3 ? 2 : 1) * MT;
+    constexpr int NWMAX = FR % 8 == 0 ? 8 : 4;
+    static_assert(FR % 4 == 0, "a ring stage is dealt to 4 or 8 waves");
+    // ring (3 weight stages) + bias of the workgroup's rows + two x_prev buffers
+    if constexpr (NWMAX == 8) {
+        if (xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64) {
+            const dim3 grid(ceil_div(N, 32 * NWMAX), g.MB), block(64 * NWMAX);
+            const size_t ldsx = (size_t)3 * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
+            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, 3, NT>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
+            return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
+        }
+    }
+    const size_t lds4 = (size_t)3 * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 128 * sizeof(float);
+    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4, 3, NT>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds4, st, xp, x0, pack,
+                       bias, H, Hp, N, g, act, out);
+    return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
+}
+
+
+// the instances of one field count: MT row tiles per wave by the geometry, nt MFMA terms by the arithmetic
+#define X3_FWD_DISPATCH_M(MV)                                                                                          \
+    (nt == 3 ? (g.MT == 2   ? launch_x3<2, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                        \
+                : g.MT == 4 ? launch_x3<4, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                        \
+                            : launch_x3<8, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, st))                       \
+             : (g.MT == 4 ? launch_x3<4, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                          \
+                          : launch_x3<8, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)))

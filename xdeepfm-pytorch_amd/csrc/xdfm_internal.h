@@ -87,6 +87,11 @@ size_t x3_fwd_pack_elems(int H, int Hp, int m);
 int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
 int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
                  int act, float* out, hipStream_t st);
+// instances for the other even field counts (cin_x3_fwd_ma.hip: m < 22, cin_x3_fwd_mb.hip: 22 < m <= 40)
+int x3_level_fwd_ma(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
+                    const X3Geom& g, int nt, int act, float* out, hipStream_t st);
+int x3_level_fwd_mb(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
+                    const X3Geom& g, int nt, int act, float* out, hipStream_t st);
 struct X3BwxGeom {
     int HBT, HBS, IB;     // h-blocks (of 16) in total / per ring stage, i-blocks (of 32)
     long NT;              // tiles = IB * m

@@ -314,6 +314,25 @@ def cin_geometry(m: int, layer_size: Sequence[int], split_half: bool):
     return levels, off
 
 
+_FALLBACK_WARNED = set()
+
+
+def _warn_if_fp32_fallback(what, probe, H, Hp, m):
+    """cin_math 1 / 2 asked for the f16 / bf16 MFMA kernels; a level they do not cover (forward: odd or > 40 field
+    count, or H <= 32 / 64 rows) runs in the fp32-MFMA kernel -- same results, about a third of the rate.  Said once
+    per shape instead of silently (the library records the arithmetic of its last launch in the probe option)."""
+    want = _lib.get_option("cin_math")
+    if want == 0 or _lib.get_option(probe) == want:
+        return
+    key = (what, want, H, Hp, m)
+    if key in _FALLBACK_WARNED:
+        return
+    _FALLBACK_WARNED.add(key)
+    import warnings
+    warnings.warn("xdfm: CIN %s level (H=%d, H_prev=%d, fields=%d) has no %s kernel; it runs in fp32-MFMA arithmetic"
+                  % (what, H, Hp, m, "f16x3" if want == 1 else "bf16"), RuntimeWarning, stacklevel=3)
+
+
 class CINStack(torch.autograd.Function):
     """All CIN levels.  x0 is FM layout [m, B*D].
 
@@ -366,6 +385,7 @@ class CINStack(torch.autograd.Function):
             bias_c = bias.contiguous()
             _lib.check(_run("cin_level_fwd", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_fwd(
                 _ptr(xp), _ptr(x0), _ptr(wf), _ptr(bias_c), H, Hp, m, N, act, _ptr(A), _stream())), "cin_level_fwd")
+            _warn_if_fp32_fallback("forward", "last_fwd_kernel", H, Hp, m)
             if pool == "sum":
                 _lib.check(lib.xdfm_cin_direct_sum(_ptr(A), dir0, drows, B, D, _ptr(result), fm, off, _stream()),
                            "cin_direct_sum")

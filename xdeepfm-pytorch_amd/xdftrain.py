@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Stand-in for the reference's xdftrain.py on the MI355X path: same command line, same flows (`--mode eval | final`),
+implemented in xdftrain_amd.py with `--model xdeepfm` and that script's defaults preselected."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import xdftrain_amd  # noqa: E402
+
+if __name__ == "__main__":
+    xdftrain_amd.main(model="xdeepfm")
