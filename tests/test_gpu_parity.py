@@ -35,12 +35,12 @@ def gclose(got, want, msg=""):
 
 def _f16x3_kernels_for(m, ls, B, D):
     """Which arithmetic each CIN kernel of a (m, layer sizes) stack must have run in cin_math 1: the f16x3 forward exists
-    for every even m in 4..40 (instances per field count) and H > 32, dX for 16 < H <= 256 (per call), dW for H > 64 with 16-byte rows (N % 4 == 0);
+    for every even m in 8..40 (instances per field count) and H > 32, dX for 16 < H <= 256 (per call), dW for H > 64 with 16-byte rows (N % 4 == 0);
     everything else falls back to the fp32-MFMA kernels -- by design, and the tests say which (no test
     asserted which kernel ran).  Returns the expected probe values of the LAST level for (fwd, bwx of level 0, bww of level 0)."""
     H_last, H0 = ls[-1], ls[0]
     N = B * D
-    fwd = 1 if (m % 2 == 0 and 4 <= m <= 40 and H_last > 32) else 0
+    fwd = 1 if (m % 2 == 0 and 8 <= m <= 40 and H_last > 32) else 0
     last_call = H0 if H0 <= 256 else (H0 % 256 or 256)     # dX walks H in calls of <= 256 rows; the probe sees the last one
     bwx = 1 if last_call > 16 else 0
     bww = 1 if (H0 > 64 and N % 4 == 0 and N >= 32) else 0
@@ -100,7 +100,7 @@ def test_cin_layer_vs_reference_golden(name, cin_math):
                                        (2, 22, 6, (40,)),                        # N = 12 < 32, odd number of column quads
                                        (9, 26, 12, (96, 34, 20)),                # Hp = 48, 17: ragged 8-row blocks
                                        # field counts other than BASELINE's 22 / 26: every even m <= 40 has f16x3 forward instances
-                                       (64, 10, 16, (64, 48)), (50, 40, 8, (72, 40)), (33, 4, 16, (128, 64)),
+                                       (64, 10, 16, (64, 48)), (50, 40, 8, (72, 40)), (33, 8, 16, (128, 64)), (13, 4, 16, (128, 64)),
                                        (12, 32, 8, (256, 40)), (17, 18, 12, (260, 48)), (21, 14, 8, (80, 36)),
                                        (11, 42, 8, (48, 40))])                   # m = 42 > 40: fp32 forward (and a warning)
 def test_cin_vs_oracle_random(B, m, D, ls, cin_math):
@@ -126,7 +126,7 @@ def test_cin_vs_oracle_random(B, m, D, ls, cin_math):
     # a level without an f16x3 forward kernel is announced (once per shape), never silent
     fell_back = [w for w in caught if "fp32-MFMA arithmetic" in str(w.message)]
     expect_fallback = cin_math == 1 and any(
-        not (m % 2 == 0 and 4 <= m <= 40 and H > 32) for H in ls)
+        not (m % 2 == 0 and 8 <= m <= 40 and H > 32) for H in ls)
     assert bool(fell_back) == expect_fallback, [str(w.message) for w in caught]
     close(out, want.detach().numpy(), msg="out")
     (out * gout.to(dev)).sum().backward()

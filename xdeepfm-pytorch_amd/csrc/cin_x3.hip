@@ -41,8 +41,9 @@ bool x3_fwd_usable(int H, int Hp, int m) {
     (void)Hp;
     const int nt = x3_terms();
     // bf16: one 1-KB fragment per row tile and step, so a ring stage of < 4 row tiles cannot be dealt to 4 waves
-    // any even field count up to 40: with an even m both lane halves walk the same compile-time (il, j) pattern
-    return nt != 0 && m >= 4 && m <= 40 && m % 2 == 0 && H > (nt == 3 ? 32 : 64);
+    // any even field count 8..40: with an even m both lane halves walk the same compile-time (il, j) pattern; a block of
+    // 8 x_prev rows must last m/2 >= ring-depth steps for the next block's rows to be landed AND published in time
+    return nt != 0 && m >= 8 && m <= 40 && m % 2 == 0 && H > (nt == 3 ? 32 : 64);
 }
 
 // |W| maximum: every block stores its partial maximum in header slot X3_HDR_PART + blockIdx.x (plain stores,

@@ -23,6 +23,28 @@ __device__ __forceinline__ f32x16 x3_mfma(const h8& a, const h8& b, const f32x16
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
 }
 
+// LDS-DMA (global_load_lds) issued as inline assembly.  Through the builtin, hipcc books the instruction on vmcnt AND on
+// lgkmcnt ("flat access that may touch LDS") and, while one is pending -- always, with a ring kept several stages ahead --
+// turns every wait for an LDS read into s_waitcnt lgkmcnt(0): look-ahead ds_reads are then waited for the moment they
+// are issued.  Hidden from the compiler, the DMA is ordered by the kernels' own counted vmcnt waits and barriers (it
+// always was), and LDS reads get counted lgkmcnt waits.  gsrc: this lane's 16 (4) bytes; lds_wave_base: wave-uniform
+// LDS byte address (x3_lds_addr), the hardware adds lane * 16 (4).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ unsigned x3_lds_addr(const void* p) {       // byte address inside the workgroup's LDS
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void x3_lds_dma16(const void* gsrc, unsigned lds_wave_base) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lo) : "memory", "m0");
+}
+__device__ __forceinline__ void x3_lds_dma4(const void* gsrc, unsigned lds_wave_base) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lo) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
+#define X3_RING 4            // ring slots of the forward kernel's weight stream (stage s + 3 is in flight while s is read)
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -80,7 +102,9 @@ __device__ __forceinline__ float x3_col_absmax(const float* __restrict__ col, lo
 // four waves through a 3-deep LDS ring filled by 16-byte LDS-DMA two steps ahead (one counted
 // s_waitcnt vmcnt + raw s_barrier per step); each wave builds its own B operand (Z hi / lo) in registers.
 // NT = MFMA terms per product: 3 (f16x3: hi / lo fp16 halves, range-fitted) or 1 (bf16 operands, no scales)
-template <int MT, int M, int NW, int R = 3, int NT = 3>
+// EXP: timing experiments compiled for one instance only (results wrong): 1 no B-operand build, 2 no barriers,
+// 4 no weight DMA inside the loop (tools/fwd_phases.py)
+template <int MT, int M, int NW, int R = X3_RING, int NT = 3, int EXP = 0>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ pack,
     const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out) {
@@ -99,16 +123,20 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const long nc = nok ? n : N - 1;
     const float nmask = nok ? 1.f : 0.f;
     const int mb = blockIdx.y;
-    const int dbg = act >> 8;                   // timing experiments (xdfm option "dbg" bits 6..11): 1 no stores, 2 one block, 8 no operand work, 16 no weight DMA
+    // timing experiments (xdfm option "dbg" bits 6..11; results become wrong): 1 no stores, 2 one block, 4 = the first
+    // lane of every workgroup writes its phase times into out[blockIdx.x * 8 ..] (shader clocks: prologue, loop,
+    // epilogue; then the same three in 100 MHz ticks) -- tools/fwd_phases.py
+    const int dbg = act >> 8;
+    const long tc0 = __builtin_readcyclecounter(), tr0 = __builtin_amdgcn_s_memrealtime();
     act &= 0xff;
 
     const char* wsrc = reinterpret_cast<const char*>(pack + X3_HDR) + (long)mb * (G.NS + 2) * STAGE + lane * 16;
+    const unsigned smem_lo = x3_lds_addr(smem);
     auto dma_stage = [&](const char* src, int slot_off) {
 #pragma unroll
         for (int k = 0; k < FPW; ++k) {
             const int f = wave * FPW + k;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + f * 1024),
-                                             (LDS_AS void*)(smem + slot_off + f * 1024), 16, 0, 0);
+            x3_lds_dma16(src + f * 1024, smem_lo + slot_off + f * 1024);
         }
     };
     // x_prev rows of a block (8 rows x the workgroup's 32*NW columns) also arrive by LDS-DMA, one block ahead, into
@@ -118,6 +146,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     constexpr int XCOLS = 32 * NW;              // columns of the workgroup
     constexpr int XPI = 8 * XCOLS / 64 / NW;    // x_prev DMA instructions per wave and block (256 B each)
     float* xbuf = reinterpret_cast<float*>(smem + R * STAGE);           // [2][8][XCOLS]
+    const unsigned xbuf_lo = smem_lo + R * STAGE;
     float* bias_s = xbuf + 2 * 8 * XCOLS;                               // [32 * MT] bias of the workgroup's rows
     if ((int)threadIdx.x < 32 * MT) {
         const int row = blockIdx.y * MT * 32 + threadIdx.x;
@@ -133,8 +162,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             i = i < Hp ? i : Hp - 1;                                    // rows past the matrix: any valid row (their factor is 0)
             long col = col0 + (e - row * XCOLS) + lane;
             col = col < N ? col : N - 1;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(xp + (long)i * N + col),
-                                             (LDS_AS void*)(xbuf + buf * 8 * XCOLS + e), 4, 0, 0);
+            x3_lds_dma4(xp + (long)i * N + col, xbuf_lo + (buf * 8 * XCOLS + e) * 4);
         }
     };
     dma_xp(0, 0);
@@ -181,10 +209,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             v[il] = xb[(ok ? hh * RH + il : 0) * XCOLS] * (ok ? sp * nmask : 0.f);
         }
     };
-    // B operand (hi, lo) of step s of a block from the block's 4 x_prev values
-    auto build_b = [&](int s, const float (&xv)[4], h8& bh, h8& bl) {
+    // B operand (hi, lo) of step s of a block from the block's 4 x_prev values; pairs t2 in [T0, T1) of its 4
+    auto build_b = [&](int s, const float (&xv)[4], h8& bh, h8& bl, int T0, int T1) {
 #pragma unroll
         for (int t2 = 0; t2 < 4; ++t2) {
+            if (t2 < T0 || t2 >= T1) continue;
             const int q = 8 * s + 2 * t2, il = q / M, j = q - il * M;
             h2 hi = h2{0, 0}, lo = h2{0, 0};
             if (il < 4) {
@@ -195,61 +224,99 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             bl[2 * t2] = lo.x; bl[2 * t2 + 1] = lo.y;
         }
     };
+    // A fragments of row-tile pair `pair` of the stage in ring slot `slot_off`
+    constexpr int TG = NT == 3 ? 2 : 4;         // row tiles per region (6 / 4 MFMAs: ~200 / 130 cycles of matrix pipe)
+    constexpr int P = MT / TG;                  // regions per step
+    static_assert(MT % TG == 0, "a step is a whole number of regions");
+    auto load_pair = [&](int slot_off, int pair, h8 (&a)[TG][FRT]) {
+        const char* st = smem + slot_off + lane * 16;
+#pragma unroll
+        for (int k = 0; k < TG; ++k)
+#pragma unroll
+            for (int f = 0; f < FRT; ++f) a[k][f] = *reinterpret_cast<const h8*>(st + (FRT * (TG * pair + k) + f) * 1024);
+    };
 
     int so[R];                                  // LDS offsets of the ring slots of steps s % R of this block
 #pragma unroll
     for (int q = 0; q < R; ++q) so[q] = q * STAGE;
     const int nblk = G.FB + (G.TS > 0 ? 1 : 0);
     float xv[4], xn[4];
-    // block 0's rows have landed (they were issued before the ring's first stages) for every wave
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 1) * FPW) : "memory");
+    // block 0's x_prev rows (issued before the ring's first stages) and stage 0 have landed, for every wave
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * FPW) : "memory");
     __builtin_amdgcn_s_barrier();
     read_xp(0, G.FB > 0 ? 4 : G.RH, xv);
     h8 bh, bl;
-    build_b(0, xv, bh, bl);
+    build_b(0, xv, bh, bl, 0, 4);
+    h8 a[TG][FRT];                              // the row tiles about to be multiplied (loaded one region ahead)
+    load_pair(so[0], 0, a);
     const char* wblk = wsrc;
+    // One step = P regions; a region multiplies one pair of row tiles (their MFMAs interleaved: no two consecutive
+    // MFMAs share an accumulator) while the NEXT region's fragments are on their way from LDS and a share of the next
+    // step's B operand is built on the VALU.  The barrier that publishes stage s + 1 sits in front of the last region
+    // of step s, whose look-ahead load is the first one to touch that stage; right behind it the slot of stage s - 1
+    // (consumed: its MFMAs were issued before the barrier) takes the DMA of stage s + R - 1.
     auto block_steps = [&](int blk, int nsteps_dyn, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const bool has_next = blk + 1 < nblk;
 #pragma unroll
         for (int s = 0; s < MP; ++s) {
             if (FULL || s < nsteps_dyn) {       // wave-uniform
-            h8 nh = bh, nl = bl;                         // operand of the step after this one, built in its shadow
-            if (dbg & 8) {
-            } else if (s + 1 < MP) {
-                if (FULL || s + 1 < nsteps_dyn) build_b(s + 1, xv, nh, nl);
-            } else if (has_next) {
-                read_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn);       // landed and published since step R - 1 of this block
-                build_b(0, xn, nh, nl);
-            }
-            // stage (blk, s) has landed for this wave's pieces; after the barrier for everyone's.  Younger than its
-            // DMA: the R - 2 stages after it, and in steps 1 .. R-2 of a block the next block's x_prev pieces (issued
-            // in step 0 right after the barrier, before that step's stage)
-            constexpr int AHEAD = R - 2;
-            if (has_next && s >= 1 && s <= AHEAD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * FPW + XPI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD * FPW) : "memory");
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (s == 0 && has_next) dma_xp(blk + 1, (blk + 1) & 1);
-            {
-                const char* src = wblk + (long)(s + R - 1) * STAGE;
-                if (!(dbg & 16)) dma_stage(src < wlast ? src : wlast, so[(s + R - 1) % R]);
-            }
-            const char* st = smem + so[s % R] + lane * 16;
+            h8 nh = bh, nl = bl;                // operand of the step after this one
+            const bool more = s + 1 < MP && (FULL || s + 1 < nsteps_dyn);
+            const bool wrap = !more && has_next;
+            if (wrap) read_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn);   // landed and published since step R - 2 of this block
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const h8 ah = *reinterpret_cast<const h8*>(st + (FRT * mt) * 1024);
-                acc[mt] = x3_mfma<NT>(ah, bh, acc[mt]);
-                if constexpr (NT == 3) {
-                    const h8 al = *reinterpret_cast<const h8*>(st + (2 * mt + 1) * 1024);
-                    acc[mt] = x3_mfma<NT>(ah, bl, acc[mt]);
-                    acc[mt] = x3_mfma<NT>(al, bh, acc[mt]);
+            for (int p = 0; p < P; ++p) {
+                h8 an[TG][FRT];
+                constexpr int NM = TG * (NT == 3 ? 3 : 1);      // MFMAs of a region, in issue order: f16x3 terms hi*hi, hi*lo, lo*hi
+                auto mfmas = [&](int i0, int i1) {
+#pragma unroll
+                    for (int i = i0; i < i1; ++i) {
+                        const int f = i / TG, k = i - f * TG;
+                        acc[TG * p + k] = x3_mfma<NT>(a[k][f == 2 ? FRT - 1 : 0], f == 1 ? bl : bh, acc[TG * p + k]);
+                    }
+                };
+                constexpr int TPR = 4 / P > 0 ? 4 / P : 1;      // B pairs built per region
+                if (p == P - 1) {
+                    // two MFMAs go ahead of the barrier: the matrix pipe has work while the waves gather
+                    mfmas(0, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // younger than stage s+1's DMA: R - 3 stages, and in steps 1 .. R-3 of a block the next block's
+                    // x_prev pieces (issued in step 0 behind the barrier, in front of that step's stage)
+                    constexpr int YOUNGER = (R - 3) * FPW;
+                    if (has_next && s >= 1 && s <= R - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER + XPI) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+                    if constexpr (!(EXP & 2)) __builtin_amdgcn_s_barrier();
+                    if (s == 0 && has_next) dma_xp(blk + 1, (blk + 1) & 1);
+                    const char* src = wblk + (long)(s + R - 1) * STAGE;
+                    if constexpr (!(EXP & 4)) dma_stage(src < wlast ? src : wlast, so[(s + R - 1) % R]);
+                    load_pair(so[(s + 1) % R], 0, an);
+                    mfmas(2, NM);
+                } else {
+                    load_pair(so[s % R], p + 1, an);
+                    mfmas(0, NM);
                 }
+                if constexpr (EXP & 1) {
+                } else if (more) build_b(s + 1, xv, nh, nl, p * TPR, p * TPR + TPR);
+                else if (wrap) build_b(0, xn, nh, nl, p * TPR, p * TPR + TPR);
+#pragma unroll
+                for (int k = 0; k < TG; ++k)
+#pragma unroll
+                    for (int f = 0; f < FRT; ++f) a[k][f] = an[k][f];
+                // issue order inside the region: the look-ahead LDS reads, then MFMAs with the VALU work spread between
+                // them (left alone, hipcc queues the VALU behind the last MFMA, where the matrix pipe runs dry)
+                __builtin_amdgcn_sched_group_barrier(0x100, TG * FRT, 0);
+#pragma unroll
+                for (int i = 0; i < (p == P - 1 ? NM - 2 : NM); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);              // regions stay regions: nothing moves across
             }
             bh = nh; bl = nl;
             }
         }
-        // next block: rotate the ring slots by the number of steps taken, first B operand
+        // next block: rotate the ring slots by the number of steps taken
         const int adv = FULL ? MP : nsteps_dyn;
         wblk += (long)adv * STAGE;
         for (int k = 0; k < adv % R; ++k) {
@@ -261,9 +328,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             for (int il = 0; il < 4; ++il) xv[il] = xn[il];
         }
     };
+    const long tc1 = __builtin_readcyclecounter(), tr1 = __builtin_amdgcn_s_memrealtime();
     for (int blk = 0; blk < ((dbg & 2) ? 1 : G.FB); ++blk) block_steps(blk, MP, std::true_type{});
     if (G.TS > 0) block_steps(G.FB, G.TS, std::false_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the two look-ahead stages must land before LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead stages must land before LDS is released
+    const long tc2 = __builtin_readcyclecounter(), tr2 = __builtin_amdgcn_s_memrealtime();
 
     // ---- epilogue: remove the scales, bias + activation, FM-layout store --------------------------
     // The bias values of the workgroup's rows sit in LDS since the prologue: their reads count on lgkmcnt, so nothing
@@ -281,6 +350,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             if (row < H && nok && (!(dbg & 1) || acc[mt][r] == 12345.f)) out[(long)row * N + n] = v;
         }
     }
+    if ((dbg & 4) && threadIdx.x == 0 && blockIdx.y == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long tc3 = __builtin_readcyclecounter(), tr3 = __builtin_amdgcn_s_memrealtime();
+        float* o = out + (long)blockIdx.x * 8;
+        o[0] = (float)(tc1 - tc0); o[1] = (float)(tc2 - tc1); o[2] = (float)(tc3 - tc2);
+        o[3] = (float)(tr1 - tr0); o[4] = (float)(tr2 - tr1); o[5] = (float)(tr3 - tr2);
+    }
 }
 
 // NW waves (= 32*NW columns) share one weight ring: 8 waves halve the L2 -> LDS traffic of the ring (every
@@ -295,13 +371,19 @@ static int launch_x3(const float* xp, const float* x0, const float* pack, const 
     if constexpr (NWMAX == 8) {
         if (xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64) {
             const dim3 grid(ceil_div(N, 32 * NWMAX), g.MB), block(64 * NWMAX);
-            const size_t ldsx = (size_t)3 * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
-            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, 3, NT>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
+            const size_t ldsx = (size_t)X3_RING * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
+            if constexpr (MT == 4 && M == 26 && NT == 3) {
+                const int e = (act >> 8) >> 3;          // dbg bits 8 / 16 / 32 -> EXP 1 / 2 / 4 (7 = all three)
+#define X3_EXP_CASE(E) if (e == E) { hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT, E>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out); return xdfm_check_launch("cin_level_fwd (experiment)"); }
+                X3_EXP_CASE(1) X3_EXP_CASE(2) X3_EXP_CASE(4) X3_EXP_CASE(7)
+#undef X3_EXP_CASE
+            }
+            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
             return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
         }
     }
-    const size_t lds4 = (size_t)3 * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 128 * sizeof(float);
-    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4, 3, NT>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds4, st, xp, x0, pack,
+    const size_t lds4 = (size_t)X3_RING * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 128 * sizeof(float);
+    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4, X3_RING, NT>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds4, st, xp, x0, pack,
                        bias, H, Hp, N, g, act, out);
     return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
 }

@@ -1,12 +1,10 @@
-// f16x3 / bf16 forward kernel instances for the field counts m in {4, 6, 8, 10, 12, 14, 16, 18, 20} (cin_x3.hip holds m = 22, 26 and the
+// f16x3 / bf16 forward kernel instances for the field counts m in {8, 10, 12, 14, 16, 18, 20} (cin_x3.hip holds m = 22, 26 and the
 // dispatch; the kernel itself is cin_x3_fwd.h).
 #include "cin_x3_fwd.h"
 
 int x3_level_fwd_ma(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
                     const X3Geom& g, int nt, int act, float* out, hipStream_t st) {
     switch (m) {
-        case 4: return X3_FWD_DISPATCH_M(4);
-        case 6: return X3_FWD_DISPATCH_M(6);
         case 8: return X3_FWD_DISPATCH_M(8);
         case 10: return X3_FWD_DISPATCH_M(10);
         case 12: return X3_FWD_DISPATCH_M(12);
