@@ -100,7 +100,7 @@ def test_cin_layer_vs_reference_golden(name, cin_math):
                                        (2, 22, 6, (40,)),                        # N = 12 < 32, odd number of column quads
                                        (9, 26, 12, (96, 34, 20)),                # Hp = 48, 17: ragged 8-row blocks
                                        # field counts other than BASELINE's 22 / 26: every even m <= 40 has f16x3 forward instances
-                                       (64, 10, 16, (64, 48)), (50, 40, 8, (72, 40)), (33, 8, 16, (128, 64)), (13, 4, 16, (128, 64)),
+                                       (64, 10, 16, (64, 48)), (50, 40, 8, (72, 40)), (33, 12, 16, (128, 64)), (13, 8, 16, (128, 64)),
                                        (12, 32, 8, (256, 40)), (17, 18, 12, (260, 48)), (21, 14, 8, (80, 36)),
                                        (11, 42, 8, (48, 40))])                   # m = 42 > 40: fp32 forward (and a warning)
 def test_cin_vs_oracle_random(B, m, D, ls, cin_math):

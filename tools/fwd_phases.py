@@ -32,6 +32,7 @@ for H, Hp, m, N, exp in shapes:
     def launch():
         _lib.check(lib.xdfm_cin_level_fwd(xp.data_ptr(), x0.data_ptr(), pack.data_ptr(), bias.data_ptr(), H, Hp, m, N, 1,
                                           out.data_ptr(), st), "fwd")
+    _lib.set_option("dbg", (exp << 3) << 6)          # the experiment's kernel, stores on: whole-launch time by events
     for _ in range(3):
         launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

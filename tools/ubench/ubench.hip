@@ -1,0 +1,163 @@
+// Machine model probes for gfx950: ticks (s_memtime) and 100 MHz ticks per instruction for the pieces of the CIN loop.
+//   hipcc --offload-arch=gfx950 -O3 -o ubench ubench.hip && ./ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int MODE>
+__global__ __launch_bounds__(512) void probe(float* out, long* t, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + blockIdx.x * 97u; x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12;
+        // two fp16 values in [-2, 2) with random mantissas
+        ((unsigned*)smem)[i] = (x & 0x83ff83ffu) | 0x3c003c00u;
+    }
+    __syncthreads();
+    f32x16 acc[4];
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+    h8 a, b, b2, fr[8];
+    f32x16 acc2[4];
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc2[k][r] = 0.f;
+    for (int r = 0; r < 8; ++r) b2[r] = (_Float16)(r * 0.25f);
+    for (int k = 0; k < 8; ++k) fr[k] = b2;
+    for (int r = 0; r < 8; ++r) { a[r] = (_Float16)(lane * 0.01f + r); b[r] = (_Float16)(r * 0.5f); }
+    float v[8];
+    for (int r = 0; r < 8; ++r) v[r] = lane + r;
+    const char* st = smem + lane * 16;
+    const long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {            // 12 independent-ish MFMAs
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k & 3], 0, 0, 0);
+        } else if (MODE == 1) {     // 12 MFMAs + 8 ds_read_b128 feeding them
+            h8 f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = *(const h8*)(st + k * 1024 + (it & 7) * 8192);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k & 7], b, acc[k & 3], 0, 0, 0);
+        } else if (MODE == 2) {     // 32 dependent-free VALU fmas
+#pragma unroll
+            for (int k = 0; k < 32; ++k) v[k & 7] = __builtin_fmaf(v[k & 7], 1.0001f, 0.5f);
+        } else if (MODE == 3) {     // 16 ds_read_b128 only
+            h8 f[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) f[k] = *(const h8*)(st + k * 1024 + (it & 3) * 16384);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) a[k & 7] += f[k][k & 7];
+        } else if (MODE == 4) {     // 12 MFMAs + 32 VALU interleaved
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k & 3], 0, 0, 0);
+                v[k & 7] = __builtin_fmaf(v[k & 7], 1.0001f, 0.5f);
+                v[(k + 3) & 7] = __builtin_fmaf(v[(k + 3) & 7], 1.0001f, 0.5f);
+                v[(k + 5) & 7] = __builtin_fmaf(v[(k + 5) & 7], 1.0001f, 0.5f);
+            }
+        } else if (MODE == 6) {     // 12 MFMAs, random operands held in registers (8 A fragments, 2 B)
+            if (it == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) fr[k] = *(const h8*)(st + k * 1024);
+                b = *(const h8*)(st + 9 * 1024); b2 = *(const h8*)(st + 10 * 1024);
+            }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[k & 7], (k & 4) ? b2 : b, acc[k & 3], 0, 0, 0);
+        } else if (MODE == 7) {     // 24 MFMAs per 8 ds_read_b128 (every fragment meets two B operands), random data
+            h8 f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = *(const h8*)(st + k * 1024 + (it & 7) * 8192);
+            if (it == 0) { b = f[3]; b2 = f[5]; }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k & 7], b, acc[k & 3], 0, 0, 0);
+                acc2[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k & 7], b2, acc2[k & 3], 0, 0, 0);
+            }
+        } else if (MODE == 8) {     // 12 MFMAs per 8 ds_read_b128, random data
+            h8 f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = *(const h8*)(st + k * 1024 + (it & 7) * 8192);
+            if (it == 0) { b = f[3]; }
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k & 7], b, acc[k & 3], 0, 0, 0);
+        } else if (MODE == 9) {     // 12 MFMAs chained through ONE accumulator
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[k & 7], b, acc[0], 0, 0, 0);
+        } else if (MODE == 10) {    // 12 MFMAs alternating between two accumulators
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[k & 7], b, acc[k & 1], 0, 0, 0);
+        } else if (MODE == 5) {     // 12 MFMAs + barrier
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k & 3], 0, 0, 0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    const long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r] + acc2[k][r];
+    for (int k = 0; k < 8; ++k) s += (float)fr[k][k];
+    for (int r = 0; r < 8; ++r) s += v[r] + (float)a[r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { t[blockIdx.x * 2] = c1 - c0; t[blockIdx.x * 2 + 1] = r1 - r0; }
+}
+
+template <int MODE>
+static void run(const char* name, int waves, int iters, int per_iter) {
+    const int blocks = 256;
+    float* out; long* t;
+    hipMalloc(&out, blocks * 512 * sizeof(float));
+    hipMalloc(&t, blocks * 2 * sizeof(long));
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(64 * waves), 65536, 0, out, t, iters);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(64 * waves), 65536, 0, out, t, iters);
+    hipEventRecord(e1, 0);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    std::vector<long> h(blocks * 2);
+    hipMemcpy(h.data(), t, blocks * 2 * sizeof(long), hipMemcpyDeviceToHost);
+    double c = 0, r = 0;
+    for (int b = 0; b < blocks; ++b) { c += h[2 * b]; r += h[2 * b + 1]; }
+    c /= blocks; r /= blocks;
+    printf("%-34s %d waves/CU: %8.1f ticks/iter (%6.2f per op, %d ops/wave/iter)  %7.1f ns/iter  tick rate %.0f MHz | events %7.1f ns/iter\n", name, waves,
+           c / iters, c / iters / per_iter, per_iter, r * 10.0 / iters, c / (r / 100.0), ms * 1e6 / iters);
+    hipFree(out); hipFree(t);
+}
+
+int main(int argc, char** argv) {
+    if (argc > 2) {                 // dependency chains
+        const int iters = atoi(argv[1]);
+        for (int waves : {4, 8}) {
+            run<0>("12 MFMA, 4 accumulators", waves, iters, 12);
+            run<10>("12 MFMA, 2 accumulators", waves, iters, 12);
+            run<9>("12 MFMA, 1 accumulator", waves, iters, 12);
+        }
+        return 0;
+    }
+    if (argc > 1) {                 // sustained load: long runs of the MFMA modes
+        const int iters = atoi(argv[1]);
+        for (int rep = 0; rep < 3; ++rep) {
+            run<0>("12 MFMA 32x32x16 f16 (long)", 8, iters, 12);
+            run<1>("12 MFMA + 8 ds_read_b128 (long)", 8, iters, 12);
+            run<4>("12 MFMA + 36 VALU (long)", 8, iters, 12);
+            run<6>("12 MFMA random regs (long)", 8, iters, 12);
+            run<8>("12 MFMA + 8 ds_read random (long)", 8, iters, 12);
+            run<7>("24 MFMA + 8 ds_read random (long)", 4, iters, 24);
+            run<7>("24 MFMA + 8 ds_read random (long)", 8, iters, 24);
+        }
+        return 0;
+    }
+    for (int waves : {4, 8}) {
+        run<0>("12 MFMA 32x32x16 f16", waves, 2000, 12);
+        run<1>("12 MFMA + 8 ds_read_b128", waves, 2000, 12);
+        run<2>("32 VALU fma", waves, 2000, 32);
+        run<3>("16 ds_read_b128", waves, 2000, 16);
+        run<4>("12 MFMA + 36 VALU", waves, 2000, 12);
+        run<5>("12 MFMA + s_barrier", waves, 2000, 12);
+    }
+    return 0;
+}

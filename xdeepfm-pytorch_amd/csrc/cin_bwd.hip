@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_kernel(
 #define LDS_AS __attribute__((address_space(3)))
 
 __device__ __forceinline__ void dma_dword(const float* g, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)lds_wave_base, 4, 0, 0);
+    x3_lds_dma4(g, x3_lds_addr(lds_wave_base));
 }
 
 template <int MT, int JT>
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void cin_bwd_w_dma_kernel(
 //   * the contraction index is re-ordered so that one ds_read_b64 feeds two k-steps: k-step t,
 //     lane half s  <->  column 4*(t>>1) + 2*s + (t&1)  (A and B operands use the same map).
 __device__ __forceinline__ void dma_x4(const float* g, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+    x3_lds_dma16(g, x3_lds_addr(lds_wave_base));
 }
 
 template <int MT, int JT>

@@ -34,6 +34,8 @@ X3Geom x3_fwd_geom(int H, int Hp, int m) {
     g.RH = (R + 1) / 2;
     g.TS = ceil_div(g.RH * m, 8);
     g.NS = g.FB * g.MP + g.TS;
+    g.SPS = x3_fwd_sps(g.MT, x3_terms() == 1 ? 1 : 3, m);
+    g.NSA = (ceil_div(g.NS, g.SPS) + 1) * g.SPS;
     return g;
 }
 
@@ -43,7 +45,7 @@ bool x3_fwd_usable(int H, int Hp, int m) {
     // bf16: one 1-KB fragment per row tile and step, so a ring stage of < 4 row tiles cannot be dealt to 4 waves
     // any even field count 8..40: with an even m both lane halves walk the same compile-time (il, j) pattern; a block of
     // 8 x_prev rows must last m/2 >= ring-depth steps for the next block's rows to be landed AND published in time
-    return nt != 0 && m >= 8 && m <= 40 && m % 2 == 0 && H > (nt == 3 ? 32 : 64);
+    return nt != 0 && m >= 2 * X3_RING && m <= 40 && m % 2 == 0 && H > (nt == 3 ? 32 : 64);
 }
 
 // |W| maximum: every block stores its partial maximum in header slot X3_HDR_PART + blockIdx.x (plain stores,
@@ -101,8 +103,8 @@ __device__ __forceinline__ void x3_fwd_pack_one(const float* __restrict__ W, int
     const int lane = (int)(idx & 63);
     long rest = idx >> 6;
     const int mt = (int)(rest % G.MT); rest /= G.MT;
-    const int g = (int)(rest % (G.NS + 2));
-    const int mb = (int)(rest / (G.NS + 2));
+    const int g = (int)(rest % G.NSA);
+    const int mb = (int)(rest / G.NSA);
     const int r = lane & 31, hh = lane >> 5;
     const int row = (mb * G.MT + mt) * 32 + r;
     int blk, s, RH;
@@ -124,25 +126,25 @@ __device__ __forceinline__ void x3_fwd_pack_one(const float* __restrict__ W, int
         }
     }
     if (nt == 3) {
-        h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (((long)mb * (G.NS + 2) + g) * G.MT + mt) * 128 + lane;
+        h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (((long)mb * G.NSA + g) * G.MT + mt) * 128 + lane;
         dst[0] = hi;
         dst[64] = lo;
     } else {
-        reinterpret_cast<h8*>(pack + X3_HDR)[(((long)mb * (G.NS + 2) + g) * G.MT + mt) * 64 + lane] = hi;
+        reinterpret_cast<h8*>(pack + X3_HDR)[(((long)mb * G.NSA + g) * G.MT + mt) * 64 + lane] = hi;
     }
 }
 
 __global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3Geom G, int nparts,
                                    float* __restrict__ pack, int nt) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < (long)G.MB * (G.NS + 2) * G.MT * 64) x3_fwd_pack_one(W, H, Hp, m, G, nparts, pack, idx, nt);
+    if (idx < (long)G.MB * G.NSA * G.MT * 64) x3_fwd_pack_one(W, H, Hp, m, G, nparts, pack, idx, nt);
 }
 
 // ---------------------------------------------------------------------------------------------
 size_t x3_fwd_pack_elems(int H, int Hp, int m) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
     // 2 KB (hi + lo) = 512 floats per (step, row tile); bf16: 1 KB
-    return (size_t)X3_HDR + (size_t)g.MB * (g.NS + 2) * g.MT * (x3_terms() == 3 ? 512 : 256);
+    return (size_t)X3_HDR + (size_t)g.MB * g.NSA * g.MT * (x3_terms() == 3 ? 512 : 256);
 }
 
 int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
@@ -150,7 +152,7 @@ int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
     const long total = (long)H * Hp * m;
     const int nt = x3_terms();
     if (nt == 3) x3_launch_absmax(W, total, pack, st);
-    const long threads = (long)g.MB * (g.NS + 2) * g.MT * 64;
+    const long threads = (long)g.MB * g.NSA * g.MT * 64;
     hipLaunchKernelGGL(x3_fwd_pack_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, st, W, H, Hp, m, g,
                        x3_absmax_blocks(total), pack, nt);
     return xdfm_check_launch("cin_fwd_pack (f16x3 / bf16)");
@@ -314,20 +316,25 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
     const long nc = nok ? n : N - 1;
     const float nmask = nok ? 1.f : 0.f;
 
+    constexpr int R = X3_BWX_RING;              // ring slots: stage k + R - 2 is in flight while k is read
     const char* wsrc = reinterpret_cast<const char*>(pack + X3_HDR) + lane * 16;
+    const char* wlast = wsrc + ((long)IB * m * SPT + 1) * STAGE;   // last stage of the stream (two spare ones close it)
+    const unsigned smem_lo = x3_lds_addr(smem);
     auto dma_stage = [&](const char* src, int slot_off) {
 #pragma unroll
         for (int k = 0; k < FPW; ++k) {
             const int f = wave * FPW + k;
-            __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)(src + f * 1024),
-                                             (LDS_AS void*)(smem + slot_off + f * 1024), 16, 0, 0);
+            x3_lds_dma16(src + f * 1024, smem_lo + slot_off + f * 1024);
         }
     };
-    dma_stage(wsrc, 0);
-    dma_stage(wsrc + STAGE, STAGE);
+#pragma unroll
+    for (int k = 0; k < R - 1; ++k) {
+        const char* src = wsrc + (long)k * STAGE;
+        dma_stage(src < wlast ? src : wlast, k * STAGE);
+    }
 
-    float* x0s = reinterpret_cast<float*>(smem + 3 * STAGE) + wave * (m * 32);     // wave-private x0[j][n0..n0+31]
-    float* dx0s = reinterpret_cast<float*>(smem + 3 * STAGE) + (NW + wave) * (m * 32);
+    float* x0s = reinterpret_cast<float*>(smem + R * STAGE) + wave * (m * 32);     // wave-private x0[j][n0..n0+31]
+    float* dx0s = reinterpret_cast<float*>(smem + R * STAGE) + (NW + wave) * (m * 32);
     {   // 4 rows of x0 in flight per pass (lane half hh takes the odd rows of a pair)
         const long nn = n0 + (lane & 31);
         const long ncl = nn < N ? nn : N - 1;
@@ -373,8 +380,16 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
     }
     const float inv = NT == 3 ? (1.f / sD) * pack[1] : 1.f;      // removes both scales from dZ
 
-    int so0 = 0, so1 = STAGE, so2 = 2 * STAGE;   // ring slot of the current stage, +1, +2
-    const char* wcur = wsrc;
+    // ring state (wave-uniform): slot of the stage being read, of the one after it, of the next DMA, and its source
+    int rd_off = 0, nx_off = STAGE, dma_off = (R - 1) * STAGE;
+    const char* dma_src = wsrc + (long)(R - 1) * STAGE;
+    // stage 0 has landed (the dOut loads above are younger than every DMA of the prologue and were waited for);
+    // the fragments of an h-block are read one h-block ahead of their MFMAs
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    h8 a[FRT];
+#pragma unroll
+    for (int f = 0; f < FRT; ++f) a[f] = *reinterpret_cast<const h8*>(smem + lane * 16 + f * 1024);
     for (int iblk = 0; iblk < IB; ++iblk) {
         float xpr[16], dxa[16];
 #pragma unroll
@@ -395,29 +410,52 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
             float psj = 0.f;
 #pragma unroll
             for (int st = 0; st < SPT; ++st) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FPW) : "memory");
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                dma_stage(wcur + 2 * STAGE, so2);
-                const char* sp = smem + so0 + lane * 16;
 #pragma unroll
                 for (int hbl = 0; hbl < HBS; ++hbl) {
                     const int hb = st * HBS + hbl;
-                    const h8 ah = *reinterpret_cast<const h8*>(sp + (FRT * hbl) * 1024);
-                    acc = x3_mfma<NT>(ah, bh[hb], acc);
+                    h8 an[FRT];
+                    if (hbl == HBS - 1) {
+                        // the next h-block opens a new stage: publish it.  One MFMA goes ahead of the barrier (the
+                        // matrix pipe has work while the waves gather); behind the barrier the slot of the stage
+                        // before this one (consumed: its MFMAs were issued) takes the DMA of stage + R - 1.
+                        acc = x3_mfma<NT>(a[0], bh[hb], acc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * FPW) : "memory");
+                        __builtin_amdgcn_s_barrier();
+                        dma_stage(dma_src < wlast ? dma_src : wlast, dma_off);
+                        dma_src += STAGE;
+                        dma_off = dma_off + STAGE == R * STAGE ? 0 : dma_off + STAGE;
+                        const char* sp = smem + nx_off + lane * 16;
+#pragma unroll
+                        for (int f = 0; f < FRT; ++f) an[f] = *reinterpret_cast<const h8*>(sp + f * 1024);
+                        rd_off = nx_off;
+                        nx_off = nx_off + STAGE == R * STAGE ? 0 : nx_off + STAGE;
+                    } else {
+                        const char* sp = smem + rd_off + lane * 16;
+#pragma unroll
+                        for (int f = 0; f < FRT; ++f) an[f] = *reinterpret_cast<const h8*>(sp + (FRT * (hbl + 1) + f) * 1024);
+                        acc = x3_mfma<NT>(a[0], bh[hb], acc);
+                    }
                     if constexpr (NT == 3) {
-                        const h8 al = *reinterpret_cast<const h8*>(sp + (2 * hbl + 1) * 1024);
-                        acc = x3_mfma<NT>(ah, bl[hb], acc);
-                        acc = x3_mfma<NT>(al, bh[hb], acc);
+                        acc = x3_mfma<NT>(a[0], bl[hb], acc);
+                        acc = x3_mfma<NT>(a[1], bh[hb], acc);
                     }
 #pragma unroll
                     for (int r = hb * RPH; r < (hb + 1) * RPH; ++r) {
                         dxa[r] = fmaf(pacc[r], px0, dxa[r]);
                         psj = fmaf(pacc[r], xpr[r], psj);
                     }
+#pragma unroll
+                    for (int f = 0; f < FRT; ++f) a[f] = an[f];
+                    // issue order: look-ahead reads first, the VALU consumption of the previous tile between the MFMAs
+                    __builtin_amdgcn_sched_group_barrier(0x100, FRT, 0);
+#pragma unroll
+                    for (int i = 0; i < (hbl == HBS - 1 ? (NT == 3 ? 2 : 0) : (NT == 3 ? 3 : 1)); ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                wcur += STAGE;
-                const int t = so0; so0 = so1; so1 = so2; so2 = t;
             }
             psj += __shfl_xor(psj, 32);
             if (hh == 0) dx0s[pj * 32 + c] += psj * inv;
@@ -519,8 +557,8 @@ static int launch_bwx3(const float* dOut, const float* xp, const float* x0, cons
     constexpr int FR = HBS * (NT == 3 ? 2 : 1);
     constexpr int NWMAX = FR % 8 == 0 ? 8 : 4;
     static_assert(FR % 4 == 0, "a ring stage is dealt to 4 or 8 waves");
-    const size_t lds8 = (size_t)3 * FR * 1024 + (size_t)2 * NWMAX * m * 32 * sizeof(float);
-    const size_t lds4 = (size_t)3 * FR * 1024 + (size_t)8 * m * 32 * sizeof(float);
+    const size_t lds8 = (size_t)X3_BWX_RING * FR * 1024 + (size_t)2 * NWMAX * m * 32 * sizeof(float);
+    const size_t lds4 = (size_t)X3_BWX_RING * FR * 1024 + (size_t)8 * m * 32 * sizeof(float);
     if (lds4 > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: m=%d needs %zu B of LDS", m, lds4);
     if (NWMAX == 8 && xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64 && lds8 <= 160 * 1024)
         hipLaunchKernelGGL((cin_bwd_x3_kernel<HBT, NWMAX, NT>), dim3(ceil_div(N, 32 * NWMAX)), dim3(64 * NWMAX), lds8, st, dOut, xp,
@@ -566,7 +604,7 @@ int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st) {
         J.nparts[l] = x3_absmax_blocks(J.nW[l]);
         J.fg[l] = x3_fwd_geom(j.H, j.Hp, j.m);
         J.bg[l] = x3_bwx_geom(j.H, j.Hp, j.m);
-        J.fthreads[l] = (long)J.fg[l].MB * (J.fg[l].NS + 2) * J.fg[l].MT * 64;
+        J.fthreads[l] = (long)J.fg[l].MB * J.fg[l].NSA * J.fg[l].MT * 64;
         J.bthreads[l] = ((long)J.bg[l].NT * J.bg[l].HBT + 2 * J.bg[l].HBS) * 64;
         if (l < L) {
             if (J.fthreads[l] > maxthreads) maxthreads = J.fthreads[l];

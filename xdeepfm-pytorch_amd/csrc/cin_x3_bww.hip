@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void x3_split_dout_kernel(const float* __restr
 // (r = row index inside its region).  A 16-byte fragment read by lanes r = 0..15 of the same logical
 // chunk then covers all 64 banks; the LDS-DMA writes lane-linear, so the XOR goes on the source address.
 __device__ __forceinline__ void x3w_dma16(const void* g, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)g, (LDS_AS void*)lds_wave_base, 16, 0, 0);
+    x3_lds_dma16(g, x3_lds_addr(lds_wave_base));
 }
 
 // hi / lo halves of the products a0*b0, a1*b1 (see x3_split_prod2 in cin_x3.hip): 5 VALU instructions per pair

@@ -23,28 +23,7 @@ __device__ __forceinline__ f32x16 x3_mfma(const h8& a, const h8& b, const f32x16
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
 }
 
-// LDS-DMA (global_load_lds) issued as inline assembly.  Through the builtin, hipcc books the instruction on vmcnt AND on
-// lgkmcnt ("flat access that may touch LDS") and, while one is pending -- always, with a ring kept several stages ahead --
-// turns every wait for an LDS read into s_waitcnt lgkmcnt(0): look-ahead ds_reads are then waited for the moment they
-// are issued.  Hidden from the compiler, the DMA is ordered by the kernels' own counted vmcnt waits and barriers (it
-// always was), and LDS reads get counted lgkmcnt waits.  gsrc: this lane's 16 (4) bytes; lds_wave_base: wave-uniform
-// LDS byte address (x3_lds_addr), the hardware adds lane * 16 (4).
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ unsigned x3_lds_addr(const void* p) {       // byte address inside the workgroup's LDS
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-__device__ __forceinline__ void x3_lds_dma16(const void* gsrc, unsigned lds_wave_base) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane(lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lo) : "memory", "m0");
-}
-__device__ __forceinline__ void x3_lds_dma4(const void* gsrc, unsigned lds_wave_base) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane(lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lo) : "memory", "m0");
-}
-#pragma clang diagnostic pop
 
-#define X3_RING 4            // ring slots of the forward kernel's weight stream (stage s + 3 is in flight while s is read)
 #define GLOBAL_AS __attribute__((address_space(1)))
 #define LDS_AS __attribute__((address_space(3)))
 
@@ -111,10 +90,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MP = M / 2;
     constexpr int FRT = NT == 3 ? 2 : 1;        // 1-KB fragments per row tile (hi, lo | bf16)
-    constexpr int FR = FRT * MT;                // 1-KB fragments per stage
-    constexpr int STAGE = FR * 1024;            // bytes
-    constexpr int FPW = FR / NW;                // LDS-DMA instructions per wave and stage
-    static_assert(FR % NW == 0, "every wave issues the same number of LDS-DMA pieces");
+    constexpr int FR = FRT * MT;                // 1-KB fragments per step
+    constexpr int STEPB = FR * 1024;            // bytes of packed weights per step
+    constexpr int SPS = x3_fwd_sps(MT, NT, M);  // steps per ring stage: one barrier and one DMA batch per stage
+    constexpr int STAGE = SPS * STEPB;          // bytes
+    constexpr int FPW = SPS * FR / NW;          // LDS-DMA instructions per wave and stage
+    static_assert((SPS * FR) % NW == 0, "every wave issues the same number of LDS-DMA pieces");
+    static_assert(MP >= SPS * (R - 1) + 1, "the next block's x_prev rows must be published before the block's last step");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, hh = lane >> 5;
@@ -130,7 +112,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const long tc0 = __builtin_readcyclecounter(), tr0 = __builtin_amdgcn_s_memrealtime();
     act &= 0xff;
 
-    const char* wsrc = reinterpret_cast<const char*>(pack + X3_HDR) + (long)mb * (G.NS + 2) * STAGE + lane * 16;
+    const char* wsrc = reinterpret_cast<const char*>(pack + X3_HDR) + (long)mb * G.NSA * STEPB + lane * 16;
     const unsigned smem_lo = x3_lds_addr(smem);
     auto dma_stage = [&](const char* src, int slot_off) {
 #pragma unroll
@@ -166,10 +148,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
         }
     };
     dma_xp(0, 0);
-    // the ring runs R - 1 stages ahead of the step being read (R slots); the packed stream ends with 2 spare stages
-    const char* wlast = wsrc + (long)(G.NS + 1) * STAGE;      // last stage that exists (reads past it are clamped to it)
+    // the ring runs R - 1 stages ahead of the stage being read (R slots); the packed stream ends with a spare stage
+    const char* wlast = wsrc + (long)(G.NSA - SPS) * STEPB;   // last stage that exists (reads past it are clamped to it)
 #pragma unroll
-    for (int k = 0; k < R - 1; ++k) dma_stage(wsrc + (long)(k < G.NS + 2 ? k : G.NS + 1) * STAGE, k * STAGE);
+    for (int k = 0; k < R - 1; ++k) {
+        const char* src = wsrc + (long)k * STAGE;
+        dma_stage(src < wlast ? src : wlast, k * STAGE);
+    }
 
     // ---- x0 column (registers), column scales --------------------------------------------------
     float x0r[M];
@@ -236,9 +221,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             for (int f = 0; f < FRT; ++f) a[k][f] = *reinterpret_cast<const h8*>(st + (FRT * (TG * pair + k) + f) * 1024);
     };
 
-    int so[R];                                  // LDS offsets of the ring slots of steps s % R of this block
-#pragma unroll
-    for (int q = 0; q < R; ++q) so[q] = q * STAGE;
     const int nblk = G.FB + (G.TS > 0 ? 1 : 0);
     float xv[4], xn[4];
     // block 0's x_prev rows (issued before the ring's first stages) and stage 0 have landed, for every wave
@@ -248,23 +230,30 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     h8 bh, bl;
     build_b(0, xv, bh, bl, 0, 4);
     h8 a[TG][FRT];                              // the row tiles about to be multiplied (loaded one region ahead)
-    load_pair(so[0], 0, a);
-    const char* wblk = wsrc;
-    // One step = P regions; a region multiplies one pair of row tiles (their MFMAs interleaved: no two consecutive
-    // MFMAs share an accumulator) while the NEXT region's fragments are on their way from LDS and a share of the next
-    // step's B operand is built on the VALU.  The barrier that publishes stage s + 1 sits in front of the last region
-    // of step s, whose look-ahead load is the first one to touch that stage; right behind it the slot of stage s - 1
-    // (consumed: its MFMAs were issued before the barrier) takes the DMA of stage s + R - 1.
+    load_pair(0, 0, a);
+    // ring state (wave-uniform): LDS offsets of the step being multiplied and of the one after it (steps sit back to
+    // back, R * SPS of them), steps left in the current stage, where the next stage goes and where it comes from
+    int rd_off = 0, la_off = R * SPS > 1 ? STEPB : 0, left = SPS - 1;
+    int dma_off = (R - 1) * STAGE;
+    const char* dma_src = wsrc + (long)(R - 1) * STAGE;
+    bool xp_todo = false, xp_young = false;
+    // One step = P regions; a region multiplies TG row tiles (MFMAs interleaved: no two consecutive ones share an
+    // accumulator) while the NEXT region's fragments are on their way from LDS and a share of the next step's B operand
+    // is built on the VALU.  When the look-ahead read of a step's last region is the first to touch a new stage k, the
+    // barrier that publishes stage k sits in front of it (two MFMAs ahead of the barrier keep the matrix pipe fed while
+    // the waves gather); right behind the barrier the slot of stage k - 2 (consumed: its MFMAs were issued before the
+    // barrier; stage k - 1 may still have reads in flight) takes the DMA of stage k + R - 2.
     auto block_steps = [&](int blk, int nsteps_dyn, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         const bool has_next = blk + 1 < nblk;
+        xp_todo = has_next;
 #pragma unroll
         for (int s = 0; s < MP; ++s) {
             if (FULL || s < nsteps_dyn) {       // wave-uniform
             h8 nh = bh, nl = bl;                // operand of the step after this one
             const bool more = s + 1 < MP && (FULL || s + 1 < nsteps_dyn);
             const bool wrap = !more && has_next;
-            if (wrap) read_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn);   // landed and published since step R - 2 of this block
+            if (wrap) read_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn);   // landed and published R - 2 stage boundaries after the first one of this block
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 h8 an[TG][FRT];
@@ -278,22 +267,27 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
                 };
                 constexpr int TPR = 4 / P > 0 ? 4 / P : 1;      // B pairs built per region
                 if (p == P - 1) {
-                    // two MFMAs go ahead of the barrier: the matrix pipe has work while the waves gather
                     mfmas(0, 2);
                     __builtin_amdgcn_sched_barrier(0);
-                    // younger than stage s+1's DMA: R - 3 stages, and in steps 1 .. R-3 of a block the next block's
-                    // x_prev pieces (issued in step 0 behind the barrier, in front of that step's stage)
-                    constexpr int YOUNGER = (R - 3) * FPW;
-                    if (has_next && s >= 1 && s <= R - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER + XPI) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
-                    if constexpr (!(EXP & 2)) __builtin_amdgcn_s_barrier();
-                    if (s == 0 && has_next) dma_xp(blk + 1, (blk + 1) & 1);
-                    const char* src = wblk + (long)(s + R - 1) * STAGE;
-                    if constexpr (!(EXP & 4)) dma_stage(src < wlast ? src : wlast, so[(s + R - 1) % R]);
-                    load_pair(so[(s + 1) % R], 0, an);
+                    if (SPS == 1 || left == 0) {                // the next step opens a new stage
+                        // younger than that stage's DMA: R - 3 stages, and (R > 3) the x_prev pieces issued at the
+                        // previous boundary in front of that boundary's stage
+                        constexpr int YOUNGER = (R - 3) * FPW;
+                        if (R > 3 && xp_young) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER + XPI) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
+                        if constexpr (!(EXP & 2)) __builtin_amdgcn_s_barrier();
+                        xp_young = xp_todo;
+                        if (xp_todo) { dma_xp(blk + 1, (blk + 1) & 1); xp_todo = false; }
+                        if constexpr (!(EXP & 4)) dma_stage(dma_src < wlast ? dma_src : wlast, dma_off);
+                        dma_src += STAGE;
+                        dma_off = dma_off + STAGE == R * STAGE ? 0 : dma_off + STAGE;
+                        left = SPS;
+                    }
+                    left -= 1;
+                    load_pair(la_off, 0, an);
                     mfmas(2, NM);
                 } else {
-                    load_pair(so[s % R], p + 1, an);
+                    load_pair(rd_off, p + 1, an);
                     mfmas(0, NM);
                 }
                 if constexpr (EXP & 1) {
@@ -314,14 +308,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
                 __builtin_amdgcn_sched_barrier(0);              // regions stay regions: nothing moves across
             }
             bh = nh; bl = nl;
+            rd_off = la_off;
+            la_off = la_off + STEPB == R * STAGE ? 0 : la_off + STEPB;
             }
-        }
-        // next block: rotate the ring slots by the number of steps taken
-        const int adv = FULL ? MP : nsteps_dyn;
-        wblk += (long)adv * STAGE;
-        for (int k = 0; k < adv % R; ++k) {
-#pragma unroll
-            for (int q = 0; q + 1 < R; ++q) { const int t = so[q]; so[q] = so[q + 1]; so[q + 1] = t; }
         }
         if (has_next) {
 #pragma unroll
@@ -367,22 +356,23 @@ static int launch_x3(const float* xp, const float* x0, const float* pack, const 
     constexpr int FR = (NT == 3 ? 2 : 1) * MT;
     constexpr int NWMAX = FR % 8 == 0 ? 8 : 4;
     static_assert(FR % 4 == 0, "a ring stage is dealt to 4 or 8 waves");
-    // ring (3 weight stages) + bias of the workgroup's rows + two x_prev buffers
+    // ring (X3_RING stages of SPS steps) + bias of the workgroup's rows + two x_prev buffers
+    constexpr size_t RING = (size_t)X3_RING * x3_fwd_sps(MT, NT, M) * FR * 1024;
     if constexpr (NWMAX == 8) {
         if (xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64) {
             const dim3 grid(ceil_div(N, 32 * NWMAX), g.MB), block(64 * NWMAX);
-            const size_t ldsx = (size_t)X3_RING * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
+            const size_t ldsx = RING + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
             if constexpr (MT == 4 && M == 26 && NT == 3) {
                 const int e = (act >> 8) >> 3;          // dbg bits 8 / 16 / 32 -> EXP 1 / 2 / 4 (7 = all three)
 #define X3_EXP_CASE(E) if (e == E) { hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT, E>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out); return xdfm_check_launch("cin_level_fwd (experiment)"); }
-                X3_EXP_CASE(1) X3_EXP_CASE(2) X3_EXP_CASE(4) X3_EXP_CASE(7)
+                X3_EXP_CASE(1) X3_EXP_CASE(2) X3_EXP_CASE(3) X3_EXP_CASE(4) X3_EXP_CASE(5) X3_EXP_CASE(6) X3_EXP_CASE(7)
 #undef X3_EXP_CASE
             }
             hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
             return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
         }
     }
-    const size_t lds4 = (size_t)X3_RING * FR * 1024 + 32 * MT * sizeof(float) + (size_t)2 * 8 * 128 * sizeof(float);
+    const size_t lds4 = RING + 32 * MT * sizeof(float) + (size_t)2 * 8 * 128 * sizeof(float);
     hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4, X3_RING, NT>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds4, st, xp, x0, pack,
                        bias, H, Hp, N, g, act, out);
     return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");

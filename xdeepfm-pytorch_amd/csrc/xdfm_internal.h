@@ -76,10 +76,26 @@ __device__ __forceinline__ int frag_row(int r, int s) { return (r & 3) + 8 * (r 
 // 1 = bf16 operands (cin_math 2: one v_mfma_f32_32x32x16_bf16, no range fitting: bf16 has fp32's exponent), 0 = neither
 static inline int x3_terms() { const int m = xdfm_opt(OPT_CIN_MATH); return m == 1 ? 3 : (m == 2 ? 1 : 0); }
 #define X3_HDR 128        // floats in front of a packed weight stream: [0] scale, [1] 1/scale, [64..127] partial maxima of |W|
+// forward ring: R stage slots in LDS; a stage = SPS consecutive MFMA steps (one barrier per stage, not per step)
+#define X3_RING 4
+#define X3_STAGE_KB 16
+#define X3_BWX_RING 4          // dX kernel: ring slots of its weight stream
+// steps per stage for MT row tiles per wave, nt MFMA terms (3 = f16x3: 2 KB per tile and step, 1 = bf16: 1 KB) and m
+// fields: X3_STAGE_KB worth of steps, but few enough that the next block's x_prev rows (issued at the first stage
+// boundary of a block of m/2 steps, published R-2 boundaries later) are there before the block's last step
+constexpr __host__ __device__ inline int x3_fwd_sps(int MT, int nt, int m) {
+    const int stepkb = (nt == 3 ? 2 : 1) * MT;
+    int sps = X3_STAGE_KB / stepkb;
+    if (sps < 1) sps = 1;
+    const int lim = (m / 2 - 1) / (X3_RING - 1);
+    while (sps > 1 && sps > lim) sps >>= 1;
+    return sps;
+}
 struct X3Geom {
     int MT, MB;           // row tiles (of 32) per wave, row groups (blockIdx.y)
     int MP;               // MFMA steps per full block of 8 x_prev rows (= m / 2)
     int FB, RH, TS, NS;   // full blocks, rows per lane half / steps of the ragged last block, total steps
+    int SPS, NSA;         // steps per ring stage; steps stored per row group (whole stages + one spare, zero past NS)
 };
 X3Geom x3_fwd_geom(int H, int Hp, int m);
 bool x3_fwd_usable(int H, int Hp, int m);
@@ -147,3 +163,26 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
 
 bool x3_pack_all_usable(int H, int Hp, int m);
 int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st);
+
+// LDS-DMA (global_load_lds) issued as inline assembly.  Through the builtin, hipcc books the instruction on vmcnt AND on
+// lgkmcnt ("flat access that may touch LDS") and, while one is pending -- always, with a ring kept several stages ahead --
+// turns every wait for an LDS read into s_waitcnt lgkmcnt(0): look-ahead ds_reads are then waited for the moment they
+// are issued.  Hidden from the compiler, the DMA is ordered by the kernels' own counted vmcnt waits and barriers (it
+// always was), and LDS reads get counted lgkmcnt waits.  gsrc: this lane's 16 (4) bytes; lds_wave_base: wave-uniform
+// LDS byte address (x3_lds_addr), the hardware adds lane * 16 (4).
+#ifdef __HIPCC__
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ unsigned x3_lds_addr(const void* p) {       // byte address inside the workgroup's LDS
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ void x3_lds_dma16(const void* gsrc, unsigned lds_wave_base) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lo) : "memory", "m0");
+}
+__device__ __forceinline__ void x3_lds_dma4(const void* gsrc, unsigned lds_wave_base) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lo) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+#endif
