@@ -1,9 +1,10 @@
-// K7: Adam step over all parameters (one launch per 40 tensors; the embedding tables are 98 % of the bytes).
+// K7: Adam step over all parameters (one launch per 40 tensors, a 1-D grid shared out by tensor size; the embedding
+// tables are 98 % of the bytes).
 //
 // replaces torch.optim.Adam.step() for the [vocab, D] / [vocab, 1] tables (deepctr/models/basemodel.py:452
 // builds torch.optim.Adam over every parameter; the reference's tables carry dense gradients,
 // deepctr/inputs.py:168 sparse=False, so every row is updated every step).  44 M parameters at config 2 =
-// 1.2 GB of traffic per step (p, m, v read + written, g read): pure HBM streaming, 16-byte accesses, 8 loads
+// 1.2 GB of traffic per step (p, m, v read + written, g read): pure HBM streaming, 16-byte accesses, 12-16 loads
 // in flight per thread.  Arithmetic follows ATen's fused kernel (fused_adam_utils.cuh), in fp32:
 //   m = m + (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;  p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // Tensor descriptors travel BY VALUE in the kernel arguments (no device-side pointer tables to build or
@@ -20,7 +21,31 @@
 #include <vector>
 
 #define ADAM_THREADS 256
-#define ADAM_BX 128
+#define ADAM_BX 512             // most blocks one tensor gets (tools/adam_probe.py: 128 .. 4096 are within 5 % of each other, 512 best)
+#define ADAM_BLOCK_ELEMS 8192   // a tensor gets one block per this many elements: 8 float4 per thread and array
+
+// Streaming accesses: p, m, v (and the touched gradients) are read once and written once per step, 14 GB of them at
+// Criteo-card vocabularies -- non-temporal, four chunks per array and thread in flight.  tools/ubench/stream.hip is the
+// bare read-modify-write stream of the same shape: 6.4-7.3 TB/s while the three arrays total 1.9 GB, 4.4-5.5 TB/s at
+// the 7.7 GB this step sweeps -- K7 runs at 5.0-5.5 TB/s (tools/adam_probe.py), the rate the memory system gives
+// this footprint.
+typedef float adam_v4f __attribute__((ext_vector_type(4)));
+// wave-uniform chunk pointer + this lane's byte offset (32-bit: the access becomes scalar base + vector offset)
+__device__ __forceinline__ float4* at4(float4* base, unsigned byte_off) {
+    return reinterpret_cast<float4*>(reinterpret_cast<char*>(base) + byte_off);
+}
+template <bool NT>
+__device__ __forceinline__ float4 adam_ld(const float4* a) {
+    if constexpr (!NT) return *a;
+    const adam_v4f t = __builtin_nontemporal_load(reinterpret_cast<const adam_v4f*>(a));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+template <bool NT>
+__device__ __forceinline__ void adam_st(float4* a, const float4& x) {
+    if constexpr (!NT) { *a = x; return; }
+    const adam_v4f t = {x.x, x.y, x.z, x.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<adam_v4f*>(a));
+}
 
 struct AdamCoef { float w1, b2, w2, lr, eps; };
 
@@ -35,18 +60,23 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 #define ADAM_CHUNK 40
-struct AdamBatch { xdfm_adam_tensor t[ADAM_CHUNK]; };
+// first[k] = first block of tensor k in the launch's 1-D grid (first[cnt] = grid size): a tensor's share of the grid
+// follows its size, so a launch that holds four 10 M-row tables and thirty small tensors is 16 000 blocks of table
+// sweep, not 128 per tensor
+struct AdamBatch { xdfm_adam_tensor t[ADAM_CHUNK]; int first[ADAM_CHUNK + 1]; };
 
-__global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
-    const AdamBatch batch, int t0, double lr_arg, const double* __restrict__ lr_dev, double beta1, double beta2, double eps,
+template <bool NT>
+__global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
+    const AdamBatch batch, int cnt, int slot0, double lr_arg, const double* __restrict__ lr_dev, double beta1, double beta2, double eps,
     float* __restrict__ l2_part) {
     // the learning rate as a kernel argument, or read from device memory (a captured HIP graph then follows a
     // learning-rate schedule without being captured again)
     const double lr = lr_dev ? *lr_dev : lr_arg;
-    // gridDim.x blocks per tensor (ADAM_BX by default; fewer = a small footprint that can share the chip with an
-    // MFMA-bound kernel on another stream); the L2 partials keep their ADAM_BX slots per tensor
-    const xdfm_adam_tensor& d = batch.t[blockIdx.y];
-    const int t = t0 + blockIdx.y;
+    int ti = 0;                                        // wave-uniform search over <= 40 entries
+    for (int k = 1; k < cnt; ++k) ti += (int)blockIdx.x >= batch.first[k] ? 1 : 0;
+    const int lb = (int)blockIdx.x - batch.first[ti];  // this block among the tensor's nb blocks
+    const int nb = batch.first[ti + 1] - batch.first[ti];
+    const xdfm_adam_tensor& d = batch.t[ti];
     float* __restrict__ p = d.param;
     float* __restrict__ m = d.exp_avg;
     float* __restrict__ v = d.exp_avg_sq;
@@ -68,8 +98,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     const float l2c = *l2;
     const float g2 = 2.f * l2c;                        // d(l2 * w^2)/dw = 2 l2 w
     float sq = 0.f;
-    const long tid = (long)blockIdx.x * ADAM_THREADS + threadIdx.x;
-    const long stride = (long)gridDim.x * ADAM_THREADS;
+    const long tid = (long)lb * ADAM_THREADS + threadIdx.x;
+    const long stride = (long)nb * ADAM_THREADS;
     const bool vec = ((((size_t)p) | ((size_t)m) | ((size_t)v) | ((size_t)g)) & 15) == 0;
     const long n4 = vec ? n / 4 : 0;
     float4* p4 = reinterpret_cast<float4*>(p);
@@ -114,62 +144,88 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
     } else if (marks) {
         // sparse gradient: a chunk's mark says whether the scatter touched it; unmarked chunks are zeros by
         // construction and are not read, marked ones are read, re-zeroed and unmarked (each lane owns its chunk's
-        // mark, so nothing races).  The mark bytes are loaded first, the gradient loads sit behind them.
+        // mark, so nothing races).  Four chunks per array and thread in flight; the mark bytes are loaded first and
+        // the (rare) gradient reads sit behind one branch, so the common iteration is a straight run of 16 loads.
         // The zero is opaque to the compiler: with a literal 0 it folds fmaf(2*l2, w, 0) into a product and then
         // contracts that product into the next subtraction, which rounds differently from the dense path -- with
         // the same instruction sequence both paths give the same bits.
         float zf;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
         const float4 zero4 = make_float4(zf, zf, zf, zf);
-        for (; i + stride < n4; i += 2 * stride) {
-            const unsigned char ka = marks[i], kb = marks[i + stride];
-            float4 pa = p4[i], ma = m4[i], va = v4[i];
-            float4 pb = p4[i + stride], mb = m4[i + stride], vb = v4[i + stride];
-            float4 ga = zero4, gb = zero4;
-            if (ka) { ga = g4[i]; g4[i] = zero4; marks[i] = 0; }
-            if (kb) { gb = g4[i + stride]; g4[i + stride] = zero4; marks[i + stride] = 0; }
-            sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w) + (pb.x * pb.x + pb.y * pb.y) + (pb.z * pb.z + pb.w * pb.w);
-            ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
-            gb.x = fmaf(g2, pb.x, gb.x); gb.y = fmaf(g2, pb.y, gb.y); gb.z = fmaf(g2, pb.z, gb.z); gb.w = fmaf(g2, pb.w, gb.w);
-            adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
-            adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
-            adam_one(pb.x, gb.x, mb.x, vb.x, step_size, bc2_sqrt, c); adam_one(pb.y, gb.y, mb.y, vb.y, step_size, bc2_sqrt, c);
-            adam_one(pb.z, gb.z, mb.z, vb.z, step_size, bc2_sqrt, c); adam_one(pb.w, gb.w, mb.w, vb.w, step_size, bc2_sqrt, c);
-            p4[i] = pa; m4[i] = ma; v4[i] = va;
-            p4[i + stride] = pb; m4[i + stride] = mb; v4[i + stride] = vb;
+        // whole-block iterations: the chunk index is (wave-uniform base) + threadIdx.x, so every access is a scalar
+        // base plus one 32-bit lane offset (16 per-lane 64-bit addresses would not fit the register budget)
+        long iu = (long)lb * ADAM_THREADS;
+        const unsigned tx = threadIdx.x, tx16 = tx * 16u;
+        for (; iu + 3 * stride + ADAM_THREADS <= n4; iu += 4 * stride) {
+            unsigned char k[4];
+            float4 P[4], M[4], V[4], G[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) k[q] = (marks + (iu + q * stride))[tx];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                P[q] = adam_ld<NT>(at4(p4 + (iu + q * stride), tx16)); M[q] = adam_ld<NT>(at4(m4 + (iu + q * stride), tx16));
+                V[q] = adam_ld<NT>(at4(v4 + (iu + q * stride), tx16));
+                G[q] = zero4;
+            }
+            if (k[0] | k[1] | k[2] | k[3]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (k[q]) { G[q] = (*at4(g4 + (iu + q * stride), tx16)); (*at4(g4 + (iu + q * stride), tx16)) = zero4; (marks + (iu + q * stride))[tx] = 0; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 pa = P[q], ma = M[q], va = V[q], ga = G[q];
+                sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+                ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+                adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+                adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+                adam_st<NT>(at4(p4 + (iu + q * stride), tx16), pa); adam_st<NT>(at4(m4 + (iu + q * stride), tx16), ma);
+                adam_st<NT>(at4(v4 + (iu + q * stride), tx16), va);
+                __builtin_amdgcn_sched_barrier(0);       // one chunk's arithmetic at a time: its temporaries die before the next
+            }
         }
+        i = iu + tx;
         for (; i < n4; i += stride) {
             const unsigned char ka = marks[i];
-            float4 pa = p4[i], ma = m4[i], va = v4[i];
+            float4 pa = adam_ld<NT>(p4 + i), ma = adam_ld<NT>(m4 + i), va = adam_ld<NT>(v4 + i);
             float4 ga = zero4;
             if (ka) { ga = g4[i]; g4[i] = zero4; marks[i] = 0; }
             sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
             ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
             adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
             adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
-            p4[i] = pa; m4[i] = ma; v4[i] = va;
+            adam_st<NT>(p4 + i, pa); adam_st<NT>(m4 + i, ma); adam_st<NT>(v4 + i, va);
         }
     }
-    for (; i + stride < n4; i += 2 * stride) {            // two float4 per array in flight
-        float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
-        float4 pb = p4[i + stride], gb = g4[i + stride], mb = m4[i + stride], vb = v4[i + stride];
-        sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w) + (pb.x * pb.x + pb.y * pb.y) + (pb.z * pb.z + pb.w * pb.w);
-        ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
-        gb.x = fmaf(g2, pb.x, gb.x); gb.y = fmaf(g2, pb.y, gb.y); gb.z = fmaf(g2, pb.z, gb.z); gb.w = fmaf(g2, pb.w, gb.w);
-        adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
-        adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
-        adam_one(pb.x, gb.x, mb.x, vb.x, step_size, bc2_sqrt, c); adam_one(pb.y, gb.y, mb.y, vb.y, step_size, bc2_sqrt, c);
-        adam_one(pb.z, gb.z, mb.z, vb.z, step_size, bc2_sqrt, c); adam_one(pb.w, gb.w, mb.w, vb.w, step_size, bc2_sqrt, c);
-        p4[i] = pa; m4[i] = ma; v4[i] = va;
-        p4[i + stride] = pb; m4[i + stride] = mb; v4[i + stride] = vb;
+    long iu = i - threadIdx.x;                            // dense gradient: four float4 per array in flight
+    const unsigned tx = threadIdx.x, tx16 = tx * 16u;
+    for (; iu + 3 * stride + ADAM_THREADS <= n4; iu += 4 * stride) {
+        float4 P[4], M[4], V[4], G[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            P[q] = adam_ld<NT>(at4(p4 + (iu + q * stride), tx16)); G[q] = adam_ld<NT>(at4(g4 + (iu + q * stride), tx16));
+            M[q] = adam_ld<NT>(at4(m4 + (iu + q * stride), tx16)); V[q] = adam_ld<NT>(at4(v4 + (iu + q * stride), tx16));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 pa = P[q], ma = M[q], va = V[q], ga = G[q];
+            sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+            ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+            adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+            adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+            adam_st<NT>(at4(p4 + (iu + q * stride), tx16), pa); adam_st<NT>(at4(m4 + (iu + q * stride), tx16), ma);
+            adam_st<NT>(at4(v4 + (iu + q * stride), tx16), va);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    i = iu + tx;
     for (; i < n4; i += stride) {
-        float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+        float4 pa = adam_ld<NT>(p4 + i), ga = adam_ld<NT>(g4 + i), ma = adam_ld<NT>(m4 + i), va = adam_ld<NT>(v4 + i);
         sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
         ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
         adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
         adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
-        p4[i] = pa; m4[i] = ma; v4[i] = va;
+        adam_st<NT>(p4 + i, pa); adam_st<NT>(m4 + i, ma); adam_st<NT>(v4 + i, va);
     }
     for (long k = 4 * n4 + tid; k < n; k += stride) {
         float pa = p[k], ma = m[k], va = v[k];
@@ -183,8 +239,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_step_kernel(
         __shared__ float wsum[ADAM_THREADS / 64];
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
         __syncthreads();
-        if (threadIdx.x == 0) l2_part[(long)t * ADAM_BX + blockIdx.x] = l2c * ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
-        if (threadIdx.x < ADAM_BX - gridDim.x && blockIdx.x == 0) l2_part[(long)t * ADAM_BX + gridDim.x + threadIdx.x] = 0.f;
+        // one slot per block of the step, in launch order: the finish kernel adds them in that fixed order
+        if (threadIdx.x == 0) l2_part[slot0 + blockIdx.x] = l2c * ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
     }
 }
 
@@ -239,13 +295,25 @@ int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const d
         int cnt = 0;
         for (int k = l; k < T; k += nlaunch) batch.t[cnt++] = tensors[order[k]];
         for (int k = cnt; k < ADAM_CHUNK; ++k) batch.t[k] = batch.t[0];
-        int bx = xdfm_opt(OPT_ADAM_BX);
-        if (bx <= 0 || bx > ADAM_BX) bx = ADAM_BX;
-        hipLaunchKernelGGL(adam_step_kernel, dim3(bx, cnt), dim3(ADAM_THREADS), 0, st, batch, slot0, lr, lr_dev, beta1, beta2, eps,
-                           l2_value ? l2_ws : nullptr);
-        slot0 += cnt;
+        // blocks per tensor by size (option "adam_bx" caps them: a small footprint for experiments)
+        int cap = xdfm_opt(OPT_ADAM_BX);
+        if (cap <= 0 || cap > ADAM_BX) cap = ADAM_BX;
+        batch.first[0] = 0;
+        for (int k = 0; k < ADAM_CHUNK; ++k) {
+            long nb = k < cnt ? ceil_div(batch.t[k].numel, (long)ADAM_BLOCK_ELEMS) : 0;
+            if (k < cnt && nb < 1) nb = 1;
+            if (nb > cap) nb = cap;
+            batch.first[k + 1] = batch.first[k] + (int)nb;
+        }
+        if (xdfm_opt(OPT_DBG) & (1 << 17))              // experiment: ordinary (cached) loads and stores
+            hipLaunchKernelGGL(adam_step_kernel<false>, dim3(batch.first[cnt]), dim3(ADAM_THREADS), 0, st, batch, cnt, slot0, lr,
+                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr);
+        else
+            hipLaunchKernelGGL(adam_step_kernel<true>, dim3(batch.first[cnt]), dim3(ADAM_THREADS), 0, st, batch, cnt, slot0, lr,
+                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr);
+        slot0 += batch.first[cnt];
     }
-    if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(1024), 0, st, l2_ws, T * ADAM_BX, l2_value);
+    if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(1024), 0, st, l2_ws, slot0, l2_value);
     return xdfm_check_launch("adam_step");
 }
 
