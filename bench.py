@@ -295,11 +295,16 @@ def main():
             step then runs from eager launches (events cannot be recorded inside a replayed HIP graph)."""
             for s in range(warmup):
                 train_step(self.model, *self.batches[s % self.n_res], dp)
+            flush = getattr(self.model.optim, "flush", None)
+            if flush is not None:
+                flush()                                      # deferred table update: the region starts with nothing owed ...
             barrier()
             ops.PROFILE = [] if kernel_events else None     # (name, work, start_event, end_event) per heavy launch
             t0 = time.perf_counter()
             for s in range(steps):
                 loss = train_step(self.model, *self.batches[s % self.n_res], dp)
+            if flush is not None:
+                flush()                                      # ... and pays everything its K steps deferred before the clock stops
             t_host = time.perf_counter() - t0
             barrier()
             dt = time.perf_counter() - t0
@@ -355,6 +360,20 @@ def main():
                  "pull) -- a deviation from the reference's dense Adam (basemodel.py:452 over sparse=False tables), off by default")
         log("lazy-Adam opt-in: %.3f ms/step" % (ldt / args.steps * 1e3))
         del lazy
+        torch.cuda.empty_cache()
+        # (3) the dense Adam sweep over every table row in every step (XDFM_ADAM_DEFERRED=0): the same bits as the default
+        # deferred update (tests/test_gpu_host.py), 24 bytes per table parameter and step of HBM traffic instead of ALU work
+        dense = Run(vocab)
+        dense.model.optim.flush()
+        dense.model.optim.deferred = False
+        dense.model.optim._invalidate()
+        ddt, _, dprof = dense.timed(args.steps, args.warmup)
+        extras["dense_adam_sweep"] = dict(
+            value=round(B * args.steps / ddt, 1), unit="examples/sec", ms_per_step=round(ddt / args.steps * 1e3, 4),
+            note="TableAdam(deferred=False): every row of every table updated in every step by the streaming kernel (K7); "
+                 "bit-identical parameters and moments")
+        log("dense Adam sweep: %.3f ms/step" % (ddt / args.steps * 1e3))
+        del dense
         torch.cuda.empty_cache()
 
     if rank == 0:

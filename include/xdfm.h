@@ -30,6 +30,8 @@
  * ABI 4: K2 is a sorted, segmented, exact reduce (no atomics; same entry points), xdfm_adam_step_lr (learning rate
  * from a device scalar), read-only options "last_fwd_kernel" / "last_bwx_kernel" / "last_bww_kernel".
  * ABI 5: attention dropout in K5 (p_drop, drop_seed on xdfm_cin_attn_pool_fwd/bwd; xdfm_cin_attn_dropout_mask).
+ * ABI 6: deferred (exact) Adam for the tables: xdfm_adam_tensor.last, XDFM_ADAM_DEFERRED, xdfm_adam_clock,
+ * xdfm_adam_step_deferred, xdfm_adam_catchup_rows, xdfm_adam_flush.
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -41,7 +43,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 5
+#define XDFM_ABI_VERSION 6
 
 enum {
     XDFM_OK = 0,
@@ -311,8 +313,11 @@ typedef struct {
      * bytes of table) instead of the vocabulary.  The reference's torch.optim.Adam over dense gradients (deepctr/
      * inputs.py:168 sparse=False, basemodel.py:452) updates every row every step: 0 keeps that arithmetic. */
     int flags;
+    /* XDFM_ADAM_DEFERRED (needs grad_marks): one byte per 16-byte chunk of param = the step (counted since the last
+     * flush, see xdfm_adam_clock) up to which the chunk's weight and moments have been updated. */
+    unsigned char* last;
 } xdfm_adam_tensor;
-enum { XDFM_ADAM_LAZY = 1 };
+enum { XDFM_ADAM_LAZY = 1, XDFM_ADAM_DEFERRED = 2 };
 size_t xdfm_adam_step_ws_elems(int T);
 int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double beta1, double beta2, double eps,
                    float* l2_ws, float* l2_value, void* stream);
@@ -321,6 +326,48 @@ int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double bet
  * instead of being captured again for every value. */
 int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const double* lr_dev, double beta1, double beta2,
                       double eps, float* l2_ws, float* l2_value, void* stream);
+
+/* ------------------------------------------------------------------ deferred Adam for the tables (K7d)
+ * Same arithmetic, same results, bit for bit, as the dense sweep above -- but the sweep's 24 bytes per table parameter
+ * and step are not moved every step.  The reference's torch.optim.Adam over dense table gradients (inputs.py:168,
+ * basemodel.py:452) updates every row every step; a row no batch touches sees the gradient 2*l2*w only, so its
+ * (w, m, v) after k untouched steps is a function of its state k steps ago and of the steps' bias corrections.  A
+ * chunk is therefore updated when it is NEEDED: before a batch gathers it (xdfm_adam_catchup_rows replays its missed
+ * steps, in registers), when a gradient arrives for it (XDFM_ADAM_DEFERRED in the step), and every F steps for all
+ * chunks (xdfm_adam_flush) -- which bounds every replay to F steps and turns the HBM-bound sweep (2.5 ms per step at
+ * 575 M parameters) into an ALU-bound one (0.63 ms per step's worth of updates, tools/ubench/replay.hip) that touches
+ * memory once per F steps.  The value of the L2 term of the replayed steps (of the weights before each replayed
+ * update) is accumulated into `backlog`: summed over an epoch it equals the dense path's.
+ * clock: device int[2] = {steps since the last flush, steps before it}; consts: device float[2*cap], the step size
+ * lr / (1 - beta1^t) and sqrt(1 - beta2^t) of the steps since the last flush, written by the step itself. */
+typedef struct {
+    int* clock;
+    float* consts;
+    int cap;            /* steps the table holds: flush before clock[0] reaches it */
+} xdfm_adam_clock;
+/* xdfm_adam_step_lr with a clock: advances it, records the step's constants, and treats XDFM_ADAM_DEFERRED tensors by
+ * their marks only (replaying, for a marked chunk, whatever steps it still misses, then this one). */
+int xdfm_adam_step_deferred(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double lr,
+                            const double* lr_dev, double beta1, double beta2, double eps, float* l2_ws, float* l2_value,
+                            void* stream);
+/* Device-side tables of one gather's fields: pointers to the rows' parameter / moment / `last` arrays, L2 strengths. */
+typedef struct {
+    float* const* param;            /* device array [m] */
+    float* const* exp_avg;
+    float* const* exp_avg_sq;
+    unsigned char* const* last;
+    const float* l2;                /* device array [m] */
+} xdfm_adam_rows;
+/* Brings the rows a batch is about to gather (X, cols, vocab as in xdfm_embed_gather_fwd; lin may be NULL) up to the
+ * clock.  ws: xdfm_adam_flush_ws_elems(0) floats.  backlog[0] += L2 value of the replayed steps. */
+int xdfm_adam_catchup_rows(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
+                           const xdfm_adam_rows* emb, const xdfm_adam_rows* lin, const xdfm_adam_clock* clk,
+                           double beta1, double beta2, double eps, float* ws, float* backlog, void* stream);
+/* Brings every chunk of the XDFM_ADAM_DEFERRED tensors up to the clock, then resets the clock (clock[1] += clock[0],
+ * clock[0] = 0, every `last` byte 0). */
+size_t xdfm_adam_flush_ws_elems(int T);
+int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double beta1, double beta2,
+                    double eps, float* ws, float* backlog, void* stream);
 
 #ifdef __cplusplus
 }

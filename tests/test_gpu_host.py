@@ -273,3 +273,106 @@ def test_entry_point_modes_run_end_to_end(tmp_path, argv, files):
         assert not any(k.startswith("val_") for k in hist) and "auc" not in hist
     else:
         assert 0.5 < hist["val_auc"][-1] <= 1.0
+
+
+def _big_vocab_model(dev, deferred, use_graph, flush_every=5):
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from xdfm_amd import graphstep
+    vocab = [5000, 31, 20003, 12, 9, 402]           # 20003 % 4 != 0: the linear table has tail rows the sweep always updates
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(ND)]
+    torch.manual_seed(4)
+    model = xDeepFM(cols, cols, dnn_hidden_units=(32, 16), cin_layer_size=(16, 8), l2_reg_dnn=1e-5, device=dev)
+    with torch.no_grad():                           # weights large enough for the L2 pull to move bits every step
+        for k, p in model.named_parameters():
+            if "embedding_dict" in k:
+                p.mul_(2000.0)
+    model.compile("adam", "binary_crossentropy", metrics=[])
+    model.optim.deferred = bool(deferred)
+    model.optim.flush_every = flush_every
+    model.train()
+    step = graphstep.GraphedStep(model)
+    step.disabled = not use_graph
+    model.__dict__["_graphed_step"] = step
+    return model, step, vocab
+
+
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
+def test_deferred_table_update_is_bit_identical_to_the_dense_sweep(use_graph):
+    """K7d (include/xdfm.h): rows are updated when gathered / when a gradient arrives / every `flush_every` steps instead
+    of every step.  Parameters, both moments and the step counters must equal the dense sweep's BIT FOR BIT -- after 23
+    steps with cold and hot rows, a learning-rate change, a prediction in the middle (flush), flushes at steps that are
+    not multiples of the period -- and the epoch's loss (data + L2 value incl. the backlog of replayed steps) must
+    agree to fp32 summation noise.  Eager launches and HIP-graph replay."""
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+
+    def run(deferred):
+        model, step, vocab = _big_vocab_model(dev, deferred, use_graph)
+        total = 0.0
+        for s in range(23):
+            if s == 9:
+                for g in model.optim.param_groups:
+                    g["lr"] = 3e-3
+            X, y = orc.synthetic_batch(256, vocab, ND, seed=500 + s)
+            out = model.train_on_batch(T(X).to(dev), T(y).to(dev))
+            total += float(out[2])
+            if s == 12:
+                model.eval()
+                with torch.no_grad():
+                    pred = model(T(X).to(dev)).clone()
+                model.train()
+        if hasattr(model.optim, "take_backlog"):
+            model.optim.flush()
+            total += model.optim.take_backlog()
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        moments = [(model.optim.state[p]["exp_avg"].clone(), model.optim.state[p]["exp_avg_sq"].clone(),
+                    float(model.optim.state[p]["step"])) for p in model.optim.param_groups[0]["params"]]
+        return model, step, sd, moments, total, pred
+
+    m_d, st_d, sd_d, mo_d, tot_d, pred_d = run(False)
+    m_l, st_l, sd_l, mo_l, tot_l, pred_l = run(True)
+    assert m_l.optim._def is not None and m_d.optim._def is None
+    if use_graph:
+        assert st_l.replays >= 15 and not st_l.disabled
+    assert torch.equal(pred_d, pred_l)
+    for k in sd_d:
+        assert torch.equal(sd_d[k], sd_l[k]), k
+    for (a, b, sa), (c, d, sb) in zip(mo_d, mo_l):
+        assert torch.equal(a, c) and torch.equal(b, d) and sa == sb
+    assert abs(tot_d - tot_l) <= 2e-6 * abs(tot_d), (tot_d, tot_l)
+
+
+def test_deferred_table_update_fit_history_and_checkpoint_match_the_dense_sweep(tmp_path):
+    """`fit` with the deferred update: the History (loss incl. the L2 term, validation metrics) equals the dense sweep's,
+    a checkpoint written in the middle holds current rows, and a user-driven step (dense gradients without marks) after
+    deferred steps is taken densely on rows that were brought up to date first."""
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+
+    def run(deferred):
+        model, _, vocab = _big_vocab_model(dev, deferred, True, flush_every=7)
+        model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
+        model.optim.deferred = bool(deferred)
+        model.optim.flush_every = 7
+        X, y = orc.synthetic_batch(3000, vocab, ND, seed=77)
+        names = list(model.feature_index.keys())
+        xd = {n: X[:, model.feature_index[n][0]] for n in names}
+        hist = model.fit(xd, y, batch_size=256, epochs=2, verbose=0, validation_split=0.1, shuffle=False)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        # one user-driven step: ordinary dense gradients
+        model.train()
+        model.optim.zero_grad()
+        out = model(T(X[:64]).to(dev))
+        torch.nn.functional.binary_cross_entropy(out.squeeze(), T(y[:64]).to(dev).squeeze(), reduction="sum").backward()
+        model.optim.step()
+        sd2 = {k: v.clone() for k, v in model.state_dict().items()}
+        return hist.history, sd, sd2
+
+    h_d, sd_d, sd2_d = run(False)
+    h_l, sd_l, sd2_l = run(True)
+    for k in h_d:
+        np.testing.assert_allclose(h_l[k], h_d[k], rtol=2e-6, atol=1e-9, err_msg=k)
+    for k in sd_d:
+        assert torch.equal(sd_d[k], sd_l[k]), k
+        assert torch.equal(sd2_d[k], sd2_l[k]), "after a user-driven step: " + k

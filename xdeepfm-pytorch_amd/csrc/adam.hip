@@ -59,6 +59,17 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p -= step_size * m / denom;
 }
 
+// One missed step of a chunk no batch touched: the gradient is the L2 term alone.  Spelled exactly like the sweep's
+// update of an unmarked chunk (gradient = fmaf(2*l2, w, opaque zero)), so a replayed step gives the sweep's bits.
+__device__ __forceinline__ void adam_replay4(float4& p, float4& m, float4& v, float step_size, float bc2_sqrt, float g2, float zf,
+                                             const AdamCoef& c, float& sq) {
+    sq += (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
+    float gx = fmaf(g2, p.x, zf), gy = fmaf(g2, p.y, zf), gz = fmaf(g2, p.z, zf), gw = fmaf(g2, p.w, zf);
+    adam_one(p.x, gx, m.x, v.x, step_size, bc2_sqrt, c); adam_one(p.y, gy, m.y, v.y, step_size, bc2_sqrt, c);
+    adam_one(p.z, gz, m.z, v.z, step_size, bc2_sqrt, c); adam_one(p.w, gw, m.w, v.w, step_size, bc2_sqrt, c);
+}
+#define ADAM_FIX 1099511627776.0          // 2^40: fixed-point scale of the L2 backlog (integer adds: order-independent)
+
 #define ADAM_CHUNK 40
 // first[k] = first block of tensor k in the launch's 1-D grid (first[cnt] = grid size): a tensor's share of the grid
 // follows its size, so a launch that holds four 10 M-row tables and thirty small tensors is 16 000 blocks of table
@@ -68,7 +79,7 @@ struct AdamBatch { xdfm_adam_tensor t[ADAM_CHUNK]; int first[ADAM_CHUNK + 1]; };
 template <bool NT>
 __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
     const AdamBatch batch, int cnt, int slot0, double lr_arg, const double* __restrict__ lr_dev, double beta1, double beta2, double eps,
-    float* __restrict__ l2_part) {
+    float* __restrict__ l2_part, const int* __restrict__ clock, const float* __restrict__ consts) {
     // the learning rate as a kernel argument, or read from device memory (a captured HIP graph then follows a
     // learning-rate schedule without being captured again)
     const double lr = lr_dev ? *lr_dev : lr_arg;
@@ -107,7 +118,62 @@ __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
     float4* v4 = reinterpret_cast<float4*>(v);
     float4* g4 = reinterpret_cast<float4*>(g);
     long i = tid;
-    if (marks && (d.flags & XDFM_ADAM_LAZY)) {
+    if (marks && (d.flags & XDFM_ADAM_DEFERRED) && clock) {
+        // deferred (exact) update, see xdfm.h: only chunks with a gradient are touched; a chunk that still misses earlier
+        // steps (its rows were not brought up to date by xdfm_adam_catchup_rows) replays them first
+        const int t = clock[0];
+        unsigned char* __restrict__ last = d.last;
+        float zf;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
+        const float4 zero4 = make_float4(zf, zf, zf, zf);
+        auto process = [&](long e) {
+            float4 pa = p4[e], ma = m4[e], va = v4[e], ga = g4[e];
+            g4[e] = zero4; marks[e] = 0;
+            for (int s = (int)last[e] + 1; s < t; ++s) adam_replay4(pa, ma, va, consts[2 * s], consts[2 * s + 1], g2, zf, c, sq);
+            sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+            ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+            adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
+            adam_one(pa.z, ga.z, ma.z, va.z, step_size, bc2_sqrt, c); adam_one(pa.w, ga.w, ma.w, va.w, step_size, bc2_sqrt, c);
+            p4[e] = pa; m4[e] = ma; v4[e] = va;
+            last[e] = (unsigned char)t;
+        };
+        // The scan reads the mark bytes 16 at a time (one uint4 per lane and load: the sweep over 144 M marks at Criteo-card
+        // vocabularies is what this step costs); the chunks in front of the first 16-byte boundary of the marks array and
+        // behind the last whole group go one by one.
+        const long head = ((16 - (long)((size_t)marks & 15)) & 15) < n4 ? ((16 - (long)((size_t)marks & 15)) & 15) : n4;
+        const long groups = (n4 - head) / 16;
+        const uint4* __restrict__ m16 = reinterpret_cast<const uint4*>(marks + head);
+        long g = tid;
+        for (; g + stride < groups; g += 2 * stride) {                       // two groups per thread in flight
+            const uint4 wa = m16[g], wb = m16[g + stride];
+            if (wa.x | wa.y | wa.z | wa.w) {
+                const unsigned w[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    if ((w[b >> 2] >> ((b & 3) * 8)) & 255u) process(head + g * 16 + b);
+            }
+            if (wb.x | wb.y | wb.z | wb.w) {
+                const unsigned w[4] = {wb.x, wb.y, wb.z, wb.w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    if ((w[b >> 2] >> ((b & 3) * 8)) & 255u) process(head + (g + stride) * 16 + b);
+            }
+        }
+        if (g < groups) {                               // this thread's last, unpaired group
+            const uint4 wa = m16[g];
+            if (wa.x | wa.y | wa.z | wa.w) {
+                const unsigned w[4] = {wa.x, wa.y, wa.z, wa.w};
+#pragma unroll
+                for (int b = 0; b < 16; ++b)
+                    if ((w[b >> 2] >> ((b & 3) * 8)) & 255u) process(head + g * 16 + b);
+            }
+        }
+        for (long e = tid; e < head; e += stride)
+            if (marks[e]) process(e);
+        for (long e = head + groups * 16 + tid; e < n4; e += stride)
+            if (marks[e]) process(e);
+        i = n4 + tid;                                   // nothing left for the dense loops below
+    } else if (marks && (d.flags & XDFM_ADAM_LAZY)) {
         // opt-in row-sparse update: chunks the batch did not touch are skipped altogether (see xdfm.h)
         float zf;
         asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
@@ -257,6 +323,134 @@ __global__ __launch_bounds__(1024) void adam_l2_finish_kernel(const float* __res
     if (threadIdx.x == 0) out[0] = acc[0];
 }
 
+// ---------------------------------------------------------------------------------------------
+// deferred Adam: clock, catch-up of the rows a batch gathers, flush (xdfm.h, "K7d")
+// ---------------------------------------------------------------------------------------------
+__global__ void adam_tick_kernel(int* __restrict__ clock, float* __restrict__ consts, int cap, double lr_arg,
+                                 const double* __restrict__ lr_dev, double beta1, double beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double lr = lr_dev ? *lr_dev : lr_arg;
+    int t = clock[0] + 1;
+    if (t >= cap) t = cap - 1;                          // the host flushes long before (defensive)
+    clock[0] = t;
+    const double step = (double)(clock[1] + t);         // the value the per-parameter step counters hold at this step
+    consts[2 * t] = (float)(lr / (1.0 - pow(beta1, step)));
+    consts[2 * t + 1] = (float)sqrt(1.0 - pow(beta2, step));
+}
+
+__global__ void adam_clock_reset_kernel(int* __restrict__ clock) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { clock[1] += clock[0]; clock[0] = 0; }
+}
+
+// block sum of l2-weighted squares in fixed point (integer adds are exact: the total does not depend on which thread
+// replayed which chunk, nor on the order of the blocks), one atomic per block
+__device__ __forceinline__ void adam_backlog_add(float v, unsigned long long* __restrict__ backlog) {
+    long long f = (long long)((double)v * ADAM_FIX);
+    for (int o = 32; o > 0; o >>= 1) f += __shfl_xor(f, o);
+    __shared__ long long part[ADAM_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long tot = 0;
+        for (int k = 0; k < ADAM_THREADS / 64; ++k) tot += part[k];
+        if (tot) atomicAdd(backlog, (unsigned long long)tot);
+    }
+}
+
+struct AdamRowsDev { float* const* p; float* const* m; float* const* v; unsigned char* const* last; const float* l2; };
+
+// One thread per (example, field, chunk of the row): the first thread to reach a chunk (CAS on the word that holds its
+// `last` byte) replays the steps it misses; duplicates of an id skip.  The gather runs in a later launch.
+__global__ __launch_bounds__(ADAM_THREADS) void adam_catchup_rows_kernel(
+    const float* __restrict__ X, long ldx, int B, const int* __restrict__ cols, const int* __restrict__ vocab, int m, int D,
+    AdamRowsDev emb, AdamRowsDev lin, int has_lin, const int* __restrict__ clock, const float* __restrict__ consts,
+    double beta1, double beta2, double eps, unsigned long long* __restrict__ backlog) {
+    const int t = clock[0];
+    const int QE = (D + 3) / 4 + ((D & 3) ? 1 : 0);     // chunks a row of D floats can straddle
+    const int QT = QE + (has_lin ? 1 : 0);
+    const long idx = (long)blockIdx.x * ADAM_THREADS + threadIdx.x;
+    float sqv = 0.f;
+    if (t > 0 && idx < (long)B * m * QT) {
+        const int q = (int)(idx % QT);
+        const long r = idx / QT;
+        const int f = (int)(r % m);
+        const long b = r / m;
+        const int V = vocab[f];
+        long id = (long)X[b * ldx + cols[f]];           // as the gather (embed.hip): truncation, clamped
+        if (id < 0 || id >= V) id = id < 0 ? 0 : V - 1;
+        const bool is_lin = q >= QE;
+        const AdamRowsDev& R = is_lin ? lin : emb;
+        const long w = is_lin ? 1 : D;
+        const long c0 = id * w / 4, c1 = (id * w + w - 1) / 4;
+        const long cc = c0 + (is_lin ? 0 : q);
+        const long n4 = (long)V * w / 4;                // whole chunks; the tail elements are updated densely every step
+        if (cc <= c1 && cc < n4) {
+            unsigned char* last = R.last[f];
+            unsigned* word = reinterpret_cast<unsigned*>(last + (cc & ~3L));
+            const int sh = (int)(cc & 3) * 8;
+            int old = -1;
+            unsigned seen = __atomic_load_n(word, __ATOMIC_RELAXED);
+            while (true) {
+                const int ob = (int)((seen >> sh) & 255u);
+                if (ob >= t) break;
+                const unsigned want = (seen & ~(255u << sh)) | ((unsigned)t << sh);
+                const unsigned got = atomicCAS(word, seen, want);
+                if (got == seen) { old = ob; break; }
+                seen = got;
+            }
+            if (old >= 0) {
+                float4* p4 = reinterpret_cast<float4*>(R.p[f]) + cc;
+                float4* m4 = reinterpret_cast<float4*>(R.m[f]) + cc;
+                float4* v4 = reinterpret_cast<float4*>(R.v[f]) + cc;
+                float4 pa = *p4, ma = *m4, va = *v4;
+                const float l2c = R.l2[f];
+                const float g2 = 2.f * l2c;
+                float zf;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
+                const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, (float)eps};
+                float sq = 0.f;
+                for (int s = old + 1; s <= t; ++s) adam_replay4(pa, ma, va, consts[2 * s], consts[2 * s + 1], g2, zf, c, sq);
+                *p4 = pa; *m4 = ma; *v4 = va;
+                sqv = l2c * sq;
+            }
+        }
+    }
+    adam_backlog_add(sqv, backlog);
+}
+
+// Every chunk of the deferred tensors up to the clock; `last` back to 0.  Same 1-D grid as the step.
+__global__ __launch_bounds__(ADAM_THREADS) void adam_flush_kernel(const AdamBatch batch, int cnt, const int* __restrict__ clock,
+                                                                  const float* __restrict__ consts, double beta1, double beta2,
+                                                                  double eps, unsigned long long* __restrict__ backlog) {
+    int ti = 0;
+    for (int k = 1; k < cnt; ++k) ti += (int)blockIdx.x >= batch.first[k] ? 1 : 0;
+    const int lb = (int)blockIdx.x - batch.first[ti];
+    const int nb = batch.first[ti + 1] - batch.first[ti];
+    const xdfm_adam_tensor& d = batch.t[ti];
+    const int t = clock[0];
+    float4* p4 = reinterpret_cast<float4*>(d.param);
+    float4* m4 = reinterpret_cast<float4*>(d.exp_avg);
+    float4* v4 = reinterpret_cast<float4*>(d.exp_avg_sq);
+    unsigned char* __restrict__ last = d.last;
+    const long n4 = d.numel / 4;
+    const float l2c = d.l2;
+    const float g2 = 2.f * l2c;
+    float zf;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
+    const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, (float)eps};
+    float sq = 0.f;
+    for (long i = (long)lb * ADAM_THREADS + threadIdx.x; i < n4; i += (long)nb * ADAM_THREADS) {
+        const int old = last[i];
+        if (old < t) {
+            float4 pa = adam_ld<true>(p4 + i), ma = adam_ld<true>(m4 + i), va = adam_ld<true>(v4 + i);
+            for (int s = old + 1; s <= t; ++s) adam_replay4(pa, ma, va, consts[2 * s], consts[2 * s + 1], g2, zf, c, sq);
+            adam_st<true>(p4 + i, pa); adam_st<true>(m4 + i, ma); adam_st<true>(v4 + i, va);
+        }
+        if (old) last[i] = 0;
+    }
+    adam_backlog_add(l2c * sq, backlog);
+}
+
 extern "C" {
 
 size_t xdfm_adam_step_ws_elems(int T) { return T > 0 ? (size_t)T * ADAM_BX : 0; }
@@ -266,8 +460,23 @@ int xdfm_adam_step(const xdfm_adam_tensor* tensors, int T, double lr, double bet
     return xdfm_adam_step_lr(tensors, T, lr, nullptr, beta1, beta2, eps, l2_ws, l2_value, stream);
 }
 
+static int adam_step_impl(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double lr, const double* lr_dev,
+                          double beta1, double beta2, double eps, float* l2_ws, float* l2_value, void* stream);
+
 int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const double* lr_dev, double beta1, double beta2,
                       double eps, float* l2_ws, float* l2_value, void* stream) {
+    return adam_step_impl(tensors, T, nullptr, lr, lr_dev, beta1, beta2, eps, l2_ws, l2_value, stream);
+}
+
+int xdfm_adam_step_deferred(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double lr,
+                            const double* lr_dev, double beta1, double beta2, double eps, float* l2_ws, float* l2_value,
+                            void* stream) {
+    XDFM_REQUIRE(clk && clk->clock && clk->consts && clk->cap > 2, "adam_step_deferred: bad clock");
+    return adam_step_impl(tensors, T, clk, lr, lr_dev, beta1, beta2, eps, l2_ws, l2_value, stream);
+}
+
+static int adam_step_impl(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double lr, const double* lr_dev,
+                          double beta1, double beta2, double eps, float* l2_ws, float* l2_value, void* stream) {
     XDFM_REQUIRE(tensors, "adam_step: null pointer");
     XDFM_REQUIRE(T > 0 && T <= 65535, "adam_step: bad tensor count %d", T);
     XDFM_REQUIRE(lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0, "adam_step: bad hyper-parameters");
@@ -278,10 +487,16 @@ int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const d
     for (int t = 0; t < T; ++t)
         XDFM_REQUIRE(!(tensors[t].flags & XDFM_ADAM_LAZY) || tensors[t].grad_marks, "adam_step: tensor %d is lazy but has no grad_marks", t);
     for (int t = 0; t < T; ++t)
+        XDFM_REQUIRE(!(tensors[t].flags & XDFM_ADAM_DEFERRED) || (clk && tensors[t].grad_marks && tensors[t].last),
+                     "adam_step: tensor %d is deferred but has no clock / grad_marks / last", t);
+    for (int t = 0; t < T; ++t)
         XDFM_REQUIRE(!tensors[t].grad_marks || ((((size_t)tensors[t].param) | ((size_t)tensors[t].grad) | ((size_t)tensors[t].exp_avg) |
                                                   ((size_t)tensors[t].exp_avg_sq)) & 15) == 0,
                      "adam_step: tensor %d has grad_marks but a pointer that is not 16-byte aligned", t);
     hipStream_t st = (hipStream_t)stream;
+    const int* clock = clk ? clk->clock : nullptr;
+    const float* consts = clk ? clk->consts : nullptr;
+    if (clk) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, st, clk->clock, clk->consts, clk->cap, lr, lr_dev, beta1, beta2);
     // Launch composition: tensors sorted by size and dealt round-robin to the launches, so that every launch streams
     // its share of the big tables and the small tensors' latency-bound blocks run underneath (a launch of small
     // tensors alone took 25 us for 30 MB).  The order is a pure function of the sizes: deterministic.
@@ -307,14 +522,65 @@ int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const d
         }
         if (xdfm_opt(OPT_DBG) & (1 << 17))              // experiment: ordinary (cached) loads and stores
             hipLaunchKernelGGL(adam_step_kernel<false>, dim3(batch.first[cnt]), dim3(ADAM_THREADS), 0, st, batch, cnt, slot0, lr,
-                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr);
+                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr, clock, consts);
         else
             hipLaunchKernelGGL(adam_step_kernel<true>, dim3(batch.first[cnt]), dim3(ADAM_THREADS), 0, st, batch, cnt, slot0, lr,
-                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr);
+                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr, clock, consts);
         slot0 += batch.first[cnt];
     }
     if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(1024), 0, st, l2_ws, slot0, l2_value);
     return xdfm_check_launch("adam_step");
+}
+
+size_t xdfm_adam_flush_ws_elems(int T) { (void)T; return 4; }    // the backlog accumulator itself: one 64-bit fixed-point cell
+
+int xdfm_adam_catchup_rows(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
+                           const xdfm_adam_rows* emb, const xdfm_adam_rows* lin, const xdfm_adam_clock* clk,
+                           double beta1, double beta2, double eps, float* ws, float* backlog, void* stream) {
+    (void)ws;
+    XDFM_REQUIRE(X && cols && vocab && emb && clk && backlog, "adam_catchup_rows: null pointer");
+    XDFM_REQUIRE(B > 0 && m > 0 && D > 0, "adam_catchup_rows: bad shape B=%d m=%d D=%d", B, m, D);
+    XDFM_REQUIRE((((size_t)backlog) & 7) == 0, "adam_catchup_rows: backlog must be 8-byte aligned");
+    const AdamRowsDev e = {emb->param, emb->exp_avg, emb->exp_avg_sq, emb->last, emb->l2};
+    const AdamRowsDev l = lin ? AdamRowsDev{lin->param, lin->exp_avg, lin->exp_avg_sq, lin->last, lin->l2} : e;
+    const int QT = (D + 3) / 4 + ((D & 3) ? 1 : 0) + (lin ? 1 : 0);
+    const long threads = (long)B * m * QT;
+    hipLaunchKernelGGL(adam_catchup_rows_kernel, dim3((unsigned)ceil_div(threads, (long)ADAM_THREADS)), dim3(ADAM_THREADS), 0,
+                       (hipStream_t)stream, X, ldx, B, cols, vocab, m, D, e, l, lin ? 1 : 0, clk->clock, clk->consts, beta1, beta2,
+                       eps, reinterpret_cast<unsigned long long*>(backlog));
+    return xdfm_check_launch("adam_catchup_rows");
+}
+
+int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double beta1, double beta2,
+                    double eps, float* ws, float* backlog, void* stream) {
+    (void)ws;
+    XDFM_REQUIRE(tensors && clk && clk->clock && clk->consts && backlog, "adam_flush: null pointer");
+    XDFM_REQUIRE((((size_t)backlog) & 7) == 0, "adam_flush: backlog must be 8-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int> order;
+    for (int t = 0; t < T; ++t)
+        if (tensors[t].flags & XDFM_ADAM_DEFERRED) {
+            XDFM_REQUIRE(tensors[t].last && tensors[t].param && tensors[t].exp_avg && tensors[t].exp_avg_sq,
+                         "adam_flush: tensor %d has a null pointer", t);
+            order.push_back(t);
+        }
+    const int n = (int)order.size();
+    for (int l0 = 0; l0 < n; l0 += ADAM_CHUNK) {
+        AdamBatch batch;
+        const int cnt = n - l0 < ADAM_CHUNK ? n - l0 : ADAM_CHUNK;
+        for (int k = 0; k < ADAM_CHUNK; ++k) batch.t[k] = tensors[order[l0 + (k < cnt ? k : 0)]];
+        batch.first[0] = 0;
+        for (int k = 0; k < ADAM_CHUNK; ++k) {
+            long nb = k < cnt ? ceil_div(batch.t[k].numel, (long)ADAM_BLOCK_ELEMS) : 0;
+            if (k < cnt && nb < 1) nb = 1;
+            if (nb > 4096) nb = 4096;
+            batch.first[k + 1] = batch.first[k] + (int)nb;
+        }
+        hipLaunchKernelGGL(adam_flush_kernel, dim3(batch.first[cnt]), dim3(ADAM_THREADS), 0, st, batch, cnt, clk->clock, clk->consts,
+                           beta1, beta2, eps, reinterpret_cast<unsigned long long*>(backlog));
+    }
+    hipLaunchKernelGGL(adam_clock_reset_kernel, dim3(1), dim3(64), 0, st, clk->clock);
+    return xdfm_check_launch("adam_flush");
 }
 
 }  // extern "C"

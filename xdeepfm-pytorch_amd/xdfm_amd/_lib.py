@@ -53,6 +53,10 @@ SIGNATURES = {
     "xdfm_adam_step_ws_elems": (c_size_t, [c_int]),
     "xdfm_adam_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, P, P, P]),
     "xdfm_adam_step_lr": (c_int, [P, c_int, c_double, P, c_double, c_double, c_double, P, P, P]),
+    "xdfm_adam_step_deferred": (c_int, [P, c_int, P, c_double, P, c_double, c_double, c_double, P, P, P]),
+    "xdfm_adam_catchup_rows": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, P, P, c_double, c_double, c_double, P, P, P]),
+    "xdfm_adam_flush_ws_elems": (c_size_t, [c_int]),
+    "xdfm_adam_flush": (c_int, [P, c_int, P, c_double, c_double, c_double, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
     "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
     "xdfm_relu_bwd_colsum": (c_int, [P, P, c_long, c_int, c_long, c_long, P, P, P, P]),
@@ -68,10 +72,21 @@ class PackJob(ctypes.Structure):
 class AdamTensor(ctypes.Structure):
     """xdfm_adam_tensor of include/xdfm.h"""
     _fields_ = [("param", c_void_p), ("grad", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p),
-                ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float), ("grad_marks", c_void_p), ("flags", c_int)]
+                ("step", c_void_p), ("numel", c_long), ("l2", ctypes.c_float), ("grad_marks", c_void_p), ("flags", c_int),
+                ("last", c_void_p)]
 
 
-ABI_VERSION = 5
+class AdamClock(ctypes.Structure):
+    """xdfm_adam_clock of include/xdfm.h"""
+    _fields_ = [("clock", c_void_p), ("consts", c_void_p), ("cap", c_int)]
+
+
+class AdamRows(ctypes.Structure):
+    """xdfm_adam_rows of include/xdfm.h (device pointer tables of one gather's fields)"""
+    _fields_ = [("param", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("last", c_void_p), ("l2", c_void_p)]
+
+
+ABI_VERSION = 6
 _lib = None
 
 

@@ -118,6 +118,8 @@ class GraphedStep(object):
                 return m._train_step_eager(x, y)
         ent.sx.copy_(x)
         ent.sy.copy_(y)
+        if dp is None and hasattr(m.optim, "note_replay"):
+            m.optim.note_replay()          # deferred table update: periodic flush, step count (the step's Python does not run)
         ent.graph.replay()
         self.replays += 1
         if dp is not None:          # captured: the first half; exchange, scatter, all-reduce and optimizer follow eagerly

@@ -157,6 +157,26 @@ class BaseModel(nn.Module):
         state["_plan"] = None
         return state
 
+    # The optimizer may hold table rows that are several steps behind (optim.TableAdam, deferred update): whoever reads
+    # or replaces the parameters as a whole -- evaluation, a checkpoint, a reload -- gets them brought up to date first.
+    def _flush_optim(self):
+        opt = self.__dict__.get("optim")
+        if opt is not None and hasattr(opt, "flush"):
+            opt.flush()
+
+    def train(self, mode=True):
+        if not mode:
+            self._flush_optim()
+        return super().train(mode)
+
+    def state_dict(self, *args, **kwargs):
+        self._flush_optim()
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._flush_optim()
+        return super().load_state_dict(*args, **kwargs)
+
     def __setstate__(self, state):
         self.__dict__.update(state)
         self.__dict__.setdefault("_plan", None)
@@ -729,6 +749,10 @@ class BaseModel(nn.Module):
                 for v in vals:
                     total_loss_epoch += v
             self._raise_on_bad_ids()          # deferred IndexError of the epoch's gathers (host is in sync here anyway)
+            if hasattr(self.optim, "take_backlog"):
+                # deferred table update: the L2 value of the steps a row was updated late for belongs to this epoch's sum
+                self.optim.flush()
+                total_loss_epoch += self.optim.take_backlog()
             epoch_logs["loss"] = total_loss_epoch / sample_num
             step_log = self.__dict__.get("_step_log")
             if step_log is not None and step_no:     # e.g. "sfg_loss": sum of the steps' values / sample_num (basemodel_sfg.py:365-366)

@@ -75,6 +75,7 @@ class EmbedPlan:
         self.stash = None         # list: gather backwards park their inputs here instead of scattering (split step)
         self.arena_on = False     # the model's train step sets this when its optimizer consumes marked gradients
         self._arenas = {}
+        self.catchup = None       # set by optim.TableAdam (deferred update): brings the rows of X up to date before they are read
 
     def on(self, device):
         key = str(device)
@@ -196,6 +197,8 @@ class EmbedGather(torch.autograd.Function):
         emb_fm = torch.empty((m, B * D), dtype=torch.float32, device=X.device)
         dnn_in = torch.empty((B, m * D + nd), dtype=torch.float32, device=X.device)
         lin = torch.empty((B, 1), dtype=torch.float32, device=X.device)
+        if plan.catchup is not None:
+            plan.catchup(plan, X, emb_tables, lin_tables)
         tp = plan.pointer_table(emb_tables, "emb")
         lp = plan.pointer_table(lin_tables, "lin") if has_lin else None
         dw = dense_w.contiguous() if (dense_w is not None and nd > 0) else None

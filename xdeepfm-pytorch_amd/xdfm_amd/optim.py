@@ -14,15 +14,26 @@ passes over the parameters (basemodel.py:412-428) from the step.
 Gradients that are views of a kept gradient buffer (`ops.GradArena`, registered through `grad_sources`) are read by
 their chunk marks: K7 skips the untouched rows of the dense table gradients and re-zeroes the touched ones."""
 import ctypes
+import os
 
 import torch
 
 from . import _lib
 
+DEFER_CAP = 256          # steps the clock's constant table holds (the `last` bytes count steps since the last flush)
+
 
 class TableAdam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lazy_rows=False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lazy_rows=False, deferred=None, flush_every=32):
         super().__init__(params, lr=lr, betas=betas, eps=eps, fused=True, capturable=True)
+        # Deferred (exact) update of the tables, include/xdfm.h "K7d": same bits as the dense sweep, but a row is brought
+        # up to date when a batch gathers it, when a gradient arrives for it, and every `flush_every` steps for all rows
+        # -- the sweep's 24 bytes per table parameter are moved once per `flush_every` steps instead of every step.
+        # Applies, like the marks, inside the model's own train step in a single process.  XDFM_ADAM_DEFERRED=0 turns it off.
+        self.deferred = (os.environ.get("XDFM_ADAM_DEFERRED", "1") != "0") if deferred is None else bool(deferred)
+        self.flush_every = max(1, min(int(flush_every), DEFER_CAP - 8))
+        self._def = None            # clock, constants, per-table `last` bytes, backlog (built by the first deferred step)
+        self._since = 0             # steps since the last flush (host count of what the device clock holds)
         # OPT-IN deviation from the reference (SURVEY 8f-1): rows of the embedding tables that a batch does not touch
         # are not updated at all (no moment decay, no L2 pull) -- "lazy" Adam.  The reference's dense Adam updates every
         # row every step; with `lazy_rows` the step's cost follows the batch instead of the vocabulary.  Applies only to
@@ -72,12 +83,125 @@ class TableAdam(torch.optim.Adam):
         self._desc = {}
         self._lr_dev = {}
         self.generation += 1
+        self._drop_deferred()
+
+    # ------------------------------------------------------------------ deferred update of the tables
+    def _drop_deferred(self):
+        d = self.__dict__.get("_def")
+        if d is not None:
+            for plan in d["plans"]:
+                plan.catchup = None
+        self._def = None
+        self._since = 0
+
+    def _deferred_state(self, dev, steps_done):
+        if self._def is None:
+            clock = torch.zeros(2, dtype=torch.int32, device=dev)
+            clock[1] = int(steps_done)
+            self._def = dict(clock=clock, consts=torch.zeros(2 * DEFER_CAP, dtype=torch.float32, device=dev),
+                             backlog=torch.zeros(1, dtype=torch.int64, device=dev), last={}, l2={}, rows={}, plans=[],
+                             tensors={})
+            self._def["clk"] = _lib.AdamClock(clock.data_ptr(), self._def["consts"].data_ptr(), DEFER_CAP)
+            for src in self.grad_sources:             # the gathers whose rows must be current before they are read
+                if hasattr(src, "catchup"):
+                    src.catchup = self._catchup
+                    self._def["plans"].append(src)
+            self.generation += 1                       # a step captured without the catch-up launch is stale
+        return self._def
+
+    def _last_bytes(self, p):
+        d = self._def
+        key = p.data_ptr()
+        hit = d["last"].get(key)
+        if hit is None:
+            hit = d["last"][key] = torch.zeros(p.numel() // 4 + 8, dtype=torch.uint8, device=p.device)
+        return hit
+
+    def _catchup(self, plan, X, emb_tables, lin_tables):
+        """Called by the gather (ops.EmbedGather.forward) before it reads the rows of X."""
+        d = self._def
+        if d is None or (self._since == 0 and not torch.cuda.is_current_stream_capturing()):
+            return
+        key = (tuple(t.data_ptr() for t in emb_tables), tuple(t.data_ptr() for t in lin_tables))
+        rows = d["rows"].get(key)
+        if rows is None:
+            def table_of(ts):
+                if not ts:
+                    return None, None
+                ent = [d["tensors"].get(t.data_ptr()) for t in ts]
+                if any(e is None for e in ent):
+                    return None, None
+                dev = ts[0].device
+                mk = lambda vals: torch.tensor(vals, dtype=torch.int64, device=dev)
+                arrs = (mk([t.data_ptr() for t in ts]), mk([e[0].data_ptr() for e in ent]), mk([e[1].data_ptr() for e in ent]),
+                        mk([e[2].data_ptr() for e in ent]), torch.tensor([e[3] for e in ent], dtype=torch.float32, device=dev))
+                return _lib.AdamRows(*[a.data_ptr() for a in arrs]), arrs
+            e_struct, e_keep = table_of(emb_tables)
+            l_struct, l_keep = table_of(lin_tables)
+            rows = d["rows"][key] = (e_struct, l_struct, e_keep, l_keep)
+        e_struct, l_struct = rows[0], rows[1]
+        if e_struct is None or (lin_tables and l_struct is None):
+            return                                      # tables this optimizer does not update by deferral
+        group = self.param_groups[0]
+        beta1, beta2 = group["betas"]
+        cols, vocab, _, _ = plan.on(X.device)
+        lib = _lib.load()
+        _lib.check(lib.xdfm_adam_catchup_rows(
+            X.data_ptr(), X.stride(0), X.shape[0], cols.data_ptr(), vocab.data_ptr(), plan.m, plan.D, ctypes.byref(e_struct),
+            ctypes.byref(l_struct) if l_struct is not None else None, ctypes.byref(d["clk"]), float(beta1), float(beta2),
+            float(group["eps"]), None, d["backlog"].data_ptr(), torch.cuda.current_stream(X.device).cuda_stream),
+            "adam_catchup_rows")
+
+    @torch.no_grad()
+    def flush(self):
+        """Every deferred chunk up to date; afterwards parameters and moments are what the dense sweep would hold."""
+        d = self.__dict__.get("_def")
+        if d is None or self._since == 0:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("xdfm TableAdam: flush inside a HIP-graph capture")
+        ent = list(d["tensors"].items())
+        if ent:
+            arr = (_lib.AdamTensor * len(ent))()
+            for k, (ptr, (m, v, last, l2, numel)) in enumerate(ent):
+                arr[k].param, arr[k].exp_avg, arr[k].exp_avg_sq, arr[k].last = ptr, m.data_ptr(), v.data_ptr(), last.data_ptr()
+                arr[k].numel, arr[k].l2, arr[k].flags = numel, l2, 2
+            group = self.param_groups[0]
+            beta1, beta2 = group["betas"]
+            dev = d["clock"].device
+            _lib.check(_lib.load().xdfm_adam_flush(ctypes.cast(arr, ctypes.c_void_p), len(ent), ctypes.byref(d["clk"]), float(beta1),
+                                                   float(beta2), float(group["eps"]), None, d["backlog"].data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream), "adam_flush")
+        self._since = 0
+
+    def take_backlog(self):
+        """L2 value of the replayed steps since the last call (a host float; syncs).  Over an epoch, the per-step L2 values
+        plus this equal the dense path's sum."""
+        d = self.__dict__.get("_def")
+        if d is None:
+            return 0.0
+        v = float(d["backlog"].item()) / float(1 << 40)
+        d["backlog"].zero_()
+        return v
+
+    def note_replay(self):
+        """Called before a captured step is replayed (its Python does not run): periodic flush, step count."""
+        if self.__dict__.get("_def") is not None:
+            if self._since >= self.flush_every:
+                self.flush()
+            self._since += 1
+
+    def state_dict(self):
+        self.flush()
+        return super().state_dict()
 
     def __getstate__(self):
         state = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
         state = dict(state)
-        for k in ("_desc", "_lr_dev", "_armed", "l2_value"):      # ctypes descriptors / device scalars: rebuilt on use
+        self.flush()
+        for k in ("_desc", "_lr_dev", "_armed", "l2_value", "_def"):      # ctypes descriptors / device scalars: rebuilt on use
             state[k] = {} if k in ("_desc", "_lr_dev") else None
+        state["_since"] = 0
         state["grad_sources"] = []
         state["lazy_rows"] = self.lazy_rows
         return state
@@ -90,6 +214,10 @@ class TableAdam(torch.optim.Adam):
         self.__dict__.setdefault("l2_value", None)
         self.__dict__.setdefault("grad_sources", [])
         self.__dict__.setdefault("lazy_rows", False)
+        self.__dict__.setdefault("deferred", False)
+        self.__dict__.setdefault("flush_every", 32)
+        self.__dict__["_def"] = None
+        self.__dict__["_since"] = 0
         self.generation = self.__dict__.get("generation", 0) + 1
 
     def owns(self, tensors):
@@ -155,18 +283,51 @@ class TableAdam(torch.optim.Adam):
                 hit = self._desc[gi] = (key, arr)
             arr = hit[1]
             arenas = [a for src in self.grad_sources for a in src.arenas() if a.pending]
+            capturing = torch.cuda.is_current_stream_capturing()
+            from . import dist as xdist
+            defer_ok = self.deferred and not self.lazy_rows and gi == 0 and xdist.current() is None
+            deferred_now = []
             for k in range(T):
                 gp = grads[k].data_ptr()
-                arr[k].grad, arr[k].grad_marks, arr[k].flags = gp, None, 0
+                arr[k].grad, arr[k].grad_marks, arr[k].flags, arr[k].last = gp, None, 0, None
                 for a in arenas:                       # a view of a kept gradient buffer: read it by its marks
                     mp = a.marks_ptr(gp)
                     if mp is not None and params[k].data_ptr() % 16 == 0:
                         arr[k].grad_marks = mp
-                        arr[k].flags = 1 if (self.lazy_rows and params[k].dim() == 2 and params[k].shape[0] > 1) else 0
+                        table = params[k].dim() == 2 and params[k].shape[0] > 1
+                        arr[k].flags = 1 if (self.lazy_rows and table) else 0
+                        if defer_ok and table:
+                            deferred_now.append(k)
                         a.consumed(gp)
                         break
-            torch._foreach_add_(steps, 1)
             dev = params[0].device
+            d = self._def
+            if d is not None and len(deferred_now) != len(d["tensors"]):
+                # tables that were deferred arrive without marks (a user-driven loop, a row-parallel run): bring
+                # everything up to date and take this step densely; the clock only notes that a step passed
+                self.flush()
+                deferred_now = []
+                d["clock"][1:2].add_(1)
+            elif deferred_now:
+                if d is None:
+                    if capturing:
+                        deferred_now = []              # state is built by an eager step, never inside a capture
+                    else:
+                        d = self._deferred_state(dev, int(round(float(steps[deferred_now[0]].item()))))
+                if d is not None:
+                    if not capturing and self._since >= self.flush_every:
+                        self.flush()
+                    for k in deferred_now:
+                        ptr = params[k].data_ptr()
+                        ent = d["tensors"].get(ptr)
+                        lk = float(l2[k]) if l2 is not None else 0.0
+                        if ent is None or ent[3] != lk:
+                            if ent is not None:
+                                self.flush()           # the L2 strength of a table changed: the replays assumed the old one
+                            ent = d["tensors"][ptr] = (exp_avgs[k], exp_avg_sqs[k], self._last_bytes(params[k]), lk, params[k].numel())
+                            d["rows"] = {}
+                        arr[k].flags, arr[k].last = 2, ent[2].data_ptr()
+            torch._foreach_add_(steps, 1)
             ws = val = None
             if l2 is not None and any(l2):
                 ws = torch.empty(lib.xdfm_adam_step_ws_elems(T), dtype=torch.float32, device=dev)
@@ -174,8 +335,17 @@ class TableAdam(torch.optim.Adam):
             stream = torch.cuda.current_stream(dev).cuda_stream
             lr_dev = self._lr_dev.get(gi)
             from . import ops                          # per-kernel timing hook of bench.py (HIP events on the launch stream)
-            nbytes = sum(params[k].numel() * (24.25 if arr[k].grad_marks else 28.0) for k in range(T))
-            _lib.check(ops._run("adam_step[bytes]", nbytes, lambda: lib.xdfm_adam_step_lr(ctypes.cast(arr, ctypes.c_void_p), T, float(group["lr"]),
+            nbytes = sum(params[k].numel() * (0.0625 if arr[k].flags == 2 else (24.25 if arr[k].grad_marks else 28.0)) for k in range(T))
+            if deferred_now and d is not None:
+                _lib.check(ops._run("adam_step[bytes]", nbytes, lambda: lib.xdfm_adam_step_deferred(
+                    ctypes.cast(arr, ctypes.c_void_p), T, ctypes.byref(d["clk"]), float(group["lr"]),
+                    lr_dev[1].data_ptr() if lr_dev is not None else None, float(beta1), float(beta2), float(group["eps"]),
+                    ws.data_ptr() if ws is not None else None, val.data_ptr() if val is not None else None, stream)),
+                    "adam_step_deferred")
+                if not capturing:
+                    self._since += 1
+            else:
+                _lib.check(ops._run("adam_step[bytes]", nbytes, lambda: lib.xdfm_adam_step_lr(ctypes.cast(arr, ctypes.c_void_p), T, float(group["lr"]),
                                              lr_dev[1].data_ptr() if lr_dev is not None else None, float(beta1),
                                              float(beta2), float(group["eps"]), ws.data_ptr() if ws is not None else None,
                                              val.data_ptr() if val is not None else None, stream)), "adam_step")
