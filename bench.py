@@ -438,6 +438,12 @@ def main():
                                     "frac": round(B * world * args.steps / dt / (HBM_PEAK_GBS * 1e9 / gather_bytes * world), 6)},
             "cin_math": CIN_MATH[math_mode][0],
             "launch": "hip_graph_replay" if replayed else "eager",
+            "optimizer": ("Adam, the reference's dense update of every table row in every step, computed DEFERRED: rows are brought "
+                          "up to date before a batch gathers them, when a gradient arrives, and every %d steps for all rows "
+                          "(bit-identical parameters and moments, tests/test_gpu_host.py); every update the timed K steps owe is "
+                          "paid inside the timed region (flush before the clock stops); `dense_adam_sweep` = the same step with "
+                          "the per-step HBM sweep" % run.model.optim.flush_every)
+            if getattr(run.model.optim, "_def", None) is not None else "Adam, dense sweep over every parameter in every step",
             "roofline": roof,
             "kernels": kernels,
         }

@@ -284,8 +284,9 @@ class TableAdam(torch.optim.Adam):
             arr = hit[1]
             arenas = [a for src in self.grad_sources for a in src.arenas() if a.pending]
             capturing = torch.cuda.is_current_stream_capturing()
-            from . import dist as xdist
-            defer_ok = self.deferred and not self.lazy_rows and gi == 0 and xdist.current() is None
+            # row-parallel runs included: a rank's own rows are brought up to date before its gather, the rows the other
+            # ranks touched arrive with their marks and are replayed inside the step -- every replica ends with the same bits
+            defer_ok = self.deferred and not self.lazy_rows and gi == 0
             deferred_now = []
             for k in range(T):
                 gp = grads[k].data_ptr()
