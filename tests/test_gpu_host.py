@@ -275,12 +275,12 @@ def test_entry_point_modes_run_end_to_end(tmp_path, argv, files):
         assert 0.5 < hist["val_auc"][-1] <= 1.0
 
 
-def _big_vocab_model(dev, deferred, use_graph, flush_every=5):
+def _big_vocab_model(dev, deferred, use_graph, flush_every=5, emb_dim=D):
     from deepctr.inputs import DenseFeat, SparseFeat
     from deepctr.models import xDeepFM
     from xdfm_amd import graphstep
-    vocab = [5000, 31, 20003, 12, 9, 402]           # 20003 % 4 != 0: the linear table has tail rows the sweep always updates
-    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(ND)]
+    vocab = [5000, 31, 20003, 3, 9, 402]            # 20003 % 4 != 0: the linear table has tail rows the sweep always updates; 3 rows: a table that is all tail
+    cols = [SparseFeat("C%d" % (i + 1), v, emb_dim) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(ND)]
     torch.manual_seed(4)
     model = xDeepFM(cols, cols, dnn_hidden_units=(32, 16), cin_layer_size=(16, 8), l2_reg_dnn=1e-5, device=dev)
     with torch.no_grad():                           # weights large enough for the L2 pull to move bits every step
@@ -297,8 +297,8 @@ def _big_vocab_model(dev, deferred, use_graph, flush_every=5):
     return model, step, vocab
 
 
-@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "graph"])
-def test_deferred_table_update_is_bit_identical_to_the_dense_sweep(use_graph):
+@pytest.mark.parametrize("use_graph,emb_dim", [(False, D), (True, D), (True, 10)], ids=["eager", "graph", "graph-D10"])
+def test_deferred_table_update_is_bit_identical_to_the_dense_sweep(use_graph, emb_dim):
     """K7d (include/xdfm.h): rows are updated when gathered / when a gradient arrives / every `flush_every` steps instead
     of every step.  Parameters, both moments and the step counters must equal the dense sweep's BIT FOR BIT -- after 23
     steps with cold and hot rows, a learning-rate change, a prediction in the middle (flush), flushes at steps that are
@@ -308,7 +308,7 @@ def test_deferred_table_update_is_bit_identical_to_the_dense_sweep(use_graph):
     dev = _dev()
 
     def run(deferred):
-        model, step, vocab = _big_vocab_model(dev, deferred, use_graph)
+        model, step, vocab = _big_vocab_model(dev, deferred, use_graph, emb_dim=emb_dim)   # D = 10 (the scripts' default): rows straddle 16-byte chunks
         total = 0.0
         for s in range(23):
             if s == 9:
