@@ -169,6 +169,13 @@ int xdfm_cin_dout(const float* A, int H, int B, int D, int act,
                   const float* dHid, int hid0, int hid_rows,
                   const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
                   float* dOut, float* dbias, void* stream);
+/* Same with a workspace of xdfm_cin_dout_ws_elems(H, B, D) floats: the per-block sums of dbias are stored and added up
+ * in a fixed order (a second tiny launch) instead of by one float atomic per block -- the same bits on every run. */
+size_t xdfm_cin_dout_ws_elems(int H, int B, int D);
+int xdfm_cin_dout_det(const float* A, int H, int B, int D, int act,
+                  const float* dHid, int hid0, int hid_rows,
+                  const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+                  float* dOut, float* dbias, float* ws, void* stream);
 
 /* dx_prev[i][n] += sum_j dZ[(i,j)][n] * x0[j][n];  dx0[j][n] += sum_i dZ[(i,j)][n] * x_prev[i][n]
  * with dZ = W^T dOut recomputed tile by tile.  dxp [Hp][N] and dx0 [m][N] are ACCUMULATED into
@@ -357,12 +364,22 @@ typedef struct {
     float* const* exp_avg_sq;
     unsigned char* const* last;
     const float* l2;                /* device array [m] */
+    float* const* grad;             /* xdfm_adam_apply_rows only: the tables' dense gradients and their mark bytes */
+    unsigned char* const* marks;
 } xdfm_adam_rows;
 /* Brings the rows a batch is about to gather (X, cols, vocab as in xdfm_embed_gather_fwd; lin may be NULL) up to the
  * clock.  ws: xdfm_adam_flush_ws_elems(0) floats.  backlog[0] += L2 value of the replayed steps. */
 int xdfm_adam_catchup_rows(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
                            const xdfm_adam_rows* emb, const xdfm_adam_rows* lin, const xdfm_adam_clock* clk,
                            double beta1, double beta2, double eps, float* ws, float* backlog, void* stream);
+/* The step's update of the deferred tables, keyed by the batch instead of by a scan of the mark bytes: for the rows of X
+ * (the batch whose gradients the scatter just wrote: single process), apply step clock[0] -- to be called after
+ * xdfm_adam_step_deferred over the OTHER tensors, which advances the clock.  Reads the rows' gradient chunks, zeroes
+ * them and their marks, updates the numel % 4 tail elements of every table densely.  l2_cell: 8-byte device scratch
+ * (zero before the first call); l2_value[0] += the L2 value of the touched rows (may be NULL). */
+int xdfm_adam_apply_rows(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
+                         const xdfm_adam_rows* emb, const xdfm_adam_rows* lin, const xdfm_adam_clock* clk,
+                         double beta1, double beta2, double eps, float* l2_cell, float* l2_value, void* stream);
 /* Brings every chunk of the XDFM_ADAM_DEFERRED tensors up to the clock, then resets the clock (clock[1] += clock[0],
  * clock[0] = 0, every `last` byte 0). */
 size_t xdfm_adam_flush_ws_elems(int T);

@@ -780,6 +780,43 @@ def test_full_size_cin_rows_vs_oracle_subset(cin_math):
         gclose(c.bias.grad, Bs[i].grad.numpy(), "db%d" % i)
 
 
+@pytest.mark.parametrize("B,D", [(4096, 16), (256, 10)])
+def test_whole_step_gradients_are_bit_identical_run_to_run(B, D, cin_math):
+    """Forward + backward of the xDeepFM step five times on one batch: the prediction and EVERY parameter gradient must
+    be the same bits each time, at BASELINE config 2's size and at the scripts' default embedding_dim = 10 (generic,
+    non-vectorised code paths).  What this pins: K2 is an exact reduce, dW sums its slabs in a fixed order, and the CIN
+    bias gradients are per-block partials added in block order (they were one float atomic per block: 16 blocks per row
+    at B = 4096 -- found by the deferred-Adam bit-equality test).  The attention variants are not covered: K5's parameter
+    gradients are accumulated with float atomics (include/xdfm.h)."""
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    vocab = [1000] * 26
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(13)]
+    torch.manual_seed(9)
+    model = xDeepFM(cols, cols, cin_layer_size=(256, 128, 128) if B > 1000 else (64, 48), l2_reg_dnn=1e-5, device=dev)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "embedding_dict" in k:
+                p.mul_(3000.0)
+    X, y = orc.synthetic_batch(B, vocab, 13, seed=11)
+    X, y = T(X).to(dev), T(y).to(dev)
+    ref = None
+    for rep in range(5):
+        model.zero_grad()
+        out = model(X)
+        torch.nn.functional.binary_cross_entropy(out.squeeze(), y.squeeze(), reduction="sum").backward()
+        got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        got["prediction"] = out.detach().clone()
+        if ref is None:
+            ref = got
+            assert len(ref) >= 60
+        else:
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), "run %d: %s differs" % (rep, k)
+
+
 def test_l2_regulariser_kernel_vs_torch():
     """K6: value and gradient of sum_t l2_t * sum(w_t^2) against the reference's per-tensor formula
     (deepctr/models/basemodel.py:412-428), on odd sizes / unaligned views."""

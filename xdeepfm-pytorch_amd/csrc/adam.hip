@@ -357,7 +357,10 @@ __device__ __forceinline__ void adam_backlog_add(float v, unsigned long long* __
     }
 }
 
-struct AdamRowsDev { float* const* p; float* const* m; float* const* v; unsigned char* const* last; const float* l2; };
+struct AdamRowsDev {
+    float* const* p; float* const* m; float* const* v; unsigned char* const* last; const float* l2;
+    float* const* g; unsigned char* const* marks;
+};
 
 // One thread per (example, field, chunk of the row): the first thread to reach a chunk (CAS on the word that holds its
 // `last` byte) replays the steps it misses; duplicates of an id skip.  The gather runs in a later launch.
@@ -416,6 +419,103 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_catchup_rows_kernel(
         }
     }
     adam_backlog_add(sqv, backlog);
+}
+
+// The step's update of the deferred tables, by the batch's rows (single process: every marked chunk belongs to a row
+// of X).  Threads [0, B*m*QT): one per (example, field, chunk of the row), first come first served through `last` as in
+// the catch-up; then 4 * m threads per table kind for the numel % 4 tail elements, which no chunk covers.
+__global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
+    const float* __restrict__ X, long ldx, int B, const int* __restrict__ cols, const int* __restrict__ vocab, int m, int D,
+    AdamRowsDev emb, AdamRowsDev lin, int has_lin, const int* __restrict__ clock, const float* __restrict__ consts,
+    double beta1, double beta2, double eps, unsigned long long* __restrict__ cell) {
+    const int t = clock[0];
+    const int QE = (D + 3) / 4 + ((D & 3) ? 1 : 0);
+    const int QT = QE + (has_lin ? 1 : 0);
+    const long idx = (long)blockIdx.x * ADAM_THREADS + threadIdx.x;
+    const long nrow = (long)B * m * QT;
+    const float ss = consts[2 * t], bc = consts[2 * t + 1];
+    const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, (float)eps};
+    float zf;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
+    float sqv = 0.f;
+    if (idx < nrow) {
+        const int q = (int)(idx % QT);
+        const long r = idx / QT;
+        const int f = (int)(r % m);
+        const long b = r / m;
+        const int V = vocab[f];
+        long id = (long)X[b * ldx + cols[f]];
+        if (id < 0 || id >= V) id = id < 0 ? 0 : V - 1;
+        const bool is_lin = q >= QE;
+        const AdamRowsDev& R = is_lin ? lin : emb;
+        const long w = is_lin ? 1 : D;
+        const long c0 = id * w / 4, c1 = (id * w + w - 1) / 4;
+        const long cc = c0 + (is_lin ? 0 : q);
+        const long n4 = (long)V * w / 4;
+        if (cc <= c1 && cc < n4) {
+            unsigned char* last = R.last[f];
+            unsigned* word = reinterpret_cast<unsigned*>(last + (cc & ~3L));
+            const int sh = (int)(cc & 3) * 8;
+            int old = -1;
+            unsigned seen = __atomic_load_n(word, __ATOMIC_RELAXED);
+            while (true) {
+                const int ob = (int)((seen >> sh) & 255u);
+                if (ob >= t) break;
+                const unsigned want = (seen & ~(255u << sh)) | ((unsigned)t << sh);
+                const unsigned got = atomicCAS(word, seen, want);
+                if (got == seen) { old = ob; break; }
+                seen = got;
+            }
+            if (old >= 0) {
+                float4* p4 = reinterpret_cast<float4*>(R.p[f]) + cc;
+                float4* m4 = reinterpret_cast<float4*>(R.m[f]) + cc;
+                float4* v4 = reinterpret_cast<float4*>(R.v[f]) + cc;
+                float4* g4 = reinterpret_cast<float4*>(R.g[f]) + cc;
+                float4 pa = *p4, ma = *m4, va = *v4, ga = *g4;
+                *g4 = make_float4(zf, zf, zf, zf);
+                R.marks[f][cc] = 0;
+                const float l2c = R.l2[f];
+                const float g2 = 2.f * l2c;
+                float sq = 0.f;
+                for (int s = old + 1; s < t; ++s) adam_replay4(pa, ma, va, consts[2 * s], consts[2 * s + 1], g2, zf, c, sq);
+                sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+                ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+                adam_one(pa.x, ga.x, ma.x, va.x, ss, bc, c); adam_one(pa.y, ga.y, ma.y, va.y, ss, bc, c);
+                adam_one(pa.z, ga.z, ma.z, va.z, ss, bc, c); adam_one(pa.w, ga.w, ma.w, va.w, ss, bc, c);
+                *p4 = pa; *m4 = ma; *v4 = va;
+                sqv = l2c * sq;
+            }
+        }
+    } else if (idx < nrow + 8L * m) {
+        // tail elements: (table kind, field, element k < 4) -- updated every step, like the sweep does
+        const long u = idx - nrow;
+        const int k = (int)(u & 3);
+        const int f = (int)((u >> 2) % m);
+        const bool is_lin = (u >> 2) >= m;
+        if (!is_lin || has_lin) {
+            const AdamRowsDev& R = is_lin ? lin : emb;
+            const long numel = (long)vocab[f] * (is_lin ? 1 : D);
+            const long e = numel / 4 * 4 + k;
+            if (e < numel) {
+                float* p = R.p[f]; float* mm = R.m[f]; float* vv = R.v[f]; float* g = R.g[f];
+                const float l2c = R.l2[f];
+                float pa = p[e], ma = mm[e], va = vv[e];
+                sqv = l2c * (pa * pa);
+                adam_one(pa, fmaf(2.f * l2c, pa, g[e]), ma, va, ss, bc, c);
+                p[e] = pa; mm[e] = ma; vv[e] = va;
+                g[e] = 0.f;
+                R.marks[f][e >> 2] = 0;
+            }
+        }
+    }
+    adam_backlog_add(sqv, cell);
+}
+
+__global__ void adam_rows_finish_kernel(unsigned long long* __restrict__ cell, float* __restrict__ l2_value) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (l2_value) l2_value[0] += (float)((double)(long long)cell[0] / ADAM_FIX);
+        cell[0] = 0ull;
+    }
 }
 
 // Every chunk of the deferred tensors up to the clock; `last` back to 0.  Same 1-D grid as the step.
@@ -541,14 +641,33 @@ int xdfm_adam_catchup_rows(const float* X, long ldx, int B, const int* cols, con
     XDFM_REQUIRE(X && cols && vocab && emb && clk && backlog, "adam_catchup_rows: null pointer");
     XDFM_REQUIRE(B > 0 && m > 0 && D > 0, "adam_catchup_rows: bad shape B=%d m=%d D=%d", B, m, D);
     XDFM_REQUIRE((((size_t)backlog) & 7) == 0, "adam_catchup_rows: backlog must be 8-byte aligned");
-    const AdamRowsDev e = {emb->param, emb->exp_avg, emb->exp_avg_sq, emb->last, emb->l2};
-    const AdamRowsDev l = lin ? AdamRowsDev{lin->param, lin->exp_avg, lin->exp_avg_sq, lin->last, lin->l2} : e;
+    const AdamRowsDev e = {emb->param, emb->exp_avg, emb->exp_avg_sq, emb->last, emb->l2, nullptr, nullptr};
+    const AdamRowsDev l = lin ? AdamRowsDev{lin->param, lin->exp_avg, lin->exp_avg_sq, lin->last, lin->l2, nullptr, nullptr} : e;
     const int QT = (D + 3) / 4 + ((D & 3) ? 1 : 0) + (lin ? 1 : 0);
     const long threads = (long)B * m * QT;
     hipLaunchKernelGGL(adam_catchup_rows_kernel, dim3((unsigned)ceil_div(threads, (long)ADAM_THREADS)), dim3(ADAM_THREADS), 0,
                        (hipStream_t)stream, X, ldx, B, cols, vocab, m, D, e, l, lin ? 1 : 0, clk->clock, clk->consts, beta1, beta2,
                        eps, reinterpret_cast<unsigned long long*>(backlog));
     return xdfm_check_launch("adam_catchup_rows");
+}
+
+int xdfm_adam_apply_rows(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
+                         const xdfm_adam_rows* emb, const xdfm_adam_rows* lin, const xdfm_adam_clock* clk,
+                         double beta1, double beta2, double eps, float* l2_cell, float* l2_value, void* stream) {
+    XDFM_REQUIRE(X && cols && vocab && emb && clk && l2_cell, "adam_apply_rows: null pointer");
+    XDFM_REQUIRE(emb->grad && emb->marks && (!lin || (lin->grad && lin->marks)), "adam_apply_rows: gradient / mark tables missing");
+    XDFM_REQUIRE(B > 0 && m > 0 && D > 0, "adam_apply_rows: bad shape B=%d m=%d D=%d", B, m, D);
+    XDFM_REQUIRE((((size_t)l2_cell) & 7) == 0, "adam_apply_rows: l2_cell must be 8-byte aligned");
+    const AdamRowsDev e = {emb->param, emb->exp_avg, emb->exp_avg_sq, emb->last, emb->l2, emb->grad, emb->marks};
+    const AdamRowsDev l = lin ? AdamRowsDev{lin->param, lin->exp_avg, lin->exp_avg_sq, lin->last, lin->l2, lin->grad, lin->marks} : e;
+    const int QT = (D + 3) / 4 + ((D & 3) ? 1 : 0) + (lin ? 1 : 0);
+    const long threads = (long)B * m * QT + 8L * m;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_apply_rows_kernel, dim3((unsigned)ceil_div(threads, (long)ADAM_THREADS)), dim3(ADAM_THREADS), 0, st, X, ldx,
+                       B, cols, vocab, m, D, e, l, lin ? 1 : 0, clk->clock, clk->consts, beta1, beta2, eps,
+                       reinterpret_cast<unsigned long long*>(l2_cell));
+    hipLaunchKernelGGL(adam_rows_finish_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(l2_cell), l2_value);
+    return xdfm_check_launch("adam_apply_rows");
 }
 
 int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double beta1, double beta2,

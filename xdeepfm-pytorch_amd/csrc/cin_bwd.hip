@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
     const float* __restrict__ A, int H, long N, int D, int act,
     const float* __restrict__ dHid, int hid0, int hid_rows,
     const float* __restrict__ dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
-    float* __restrict__ dOut, float* __restrict__ dbias) {
+    float* __restrict__ dOut, float* __restrict__ dbias, float* __restrict__ slots) {
     const int h = blockIdx.y;
     const bool has_hid = dHid && h >= hid0 && h < hid0 + hid_rows;
     const bool has_dir = dDir && h >= dir0 && h < dir0 + dir_rows;
@@ -71,7 +71,21 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
     __shared__ float wsum[4];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&dbias[h], wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (threadIdx.x == 0) {
+        const float bsum = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        // with a workspace: one slot per block, added up in block order by cin_dbias_finish_kernel (the same bits on
+        // every run); without: a float atomic per block, whose order -- and with it the last bits -- varies
+        if (slots) slots[(long)h * gridDim.x + blockIdx.x] = bsum;
+        else atomicAdd(&dbias[h], bsum);
+    }
+}
+
+__global__ void cin_dbias_finish_kernel(const float* __restrict__ part, int H, int gx, float* __restrict__ dbias) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    float s = 0.f;
+    for (int k = 0; k < gx; ++k) s += part[(long)h * gx + k];
+    dbias[h] += s;
 }
 
 // =============================================================================================
@@ -726,9 +740,25 @@ static int launch_bwd_w(const float* dOut, const float* xp, const float* x0, int
 
 extern "C" {
 
+static bool cin_dout_vec(const float* A, long N, int D, const float* dOut, const float* dh, const float* dd) {
+    return (N % 4 == 0) && (D % 4 == 0) && ((((size_t)A) | ((size_t)dOut) | ((size_t)dh) | ((size_t)dd)) & 15) == 0;
+}
+
+size_t xdfm_cin_dout_ws_elems(int H, int B, int D) {
+    if (H <= 0 || B <= 0 || D <= 0) return 0;
+    return (size_t)H * ceil_div((long)B * D, 1024);      // enough for either vector width
+}
+
 int xdfm_cin_dout(const float* A, int H, int B, int D, int act, const float* dHid, int hid0, int hid_rows,
                   const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
                   float* dOut, float* dbias, void* stream) {
+    return xdfm_cin_dout_det(A, H, B, D, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias,
+                             nullptr, stream);
+}
+
+int xdfm_cin_dout_det(const float* A, int H, int B, int D, int act, const float* dHid, int hid0, int hid_rows,
+                      const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+                      float* dOut, float* dbias, float* ws, void* stream) {
     XDFM_REQUIRE(A && dOut && dbias, "cin_dout: null pointer");
     XDFM_REQUIRE(H > 0 && B > 0 && D > 0, "cin_dout: bad shape H=%d B=%d D=%d", H, B, D);
     XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_dout: unsupported activation %d", act);
@@ -738,13 +768,15 @@ int xdfm_cin_dout(const float* A, int H, int B, int D, int act, const float* dHi
     const long N = (long)B * D;
     const float* dh = hid_rows > 0 ? dHid : nullptr;
     const float* dd = dir_rows > 0 ? dDir : nullptr;
-    const bool vec = (N % 4 == 0) && (D % 4 == 0) && ((((size_t)A) | ((size_t)dOut) | ((size_t)dh) | ((size_t)dd)) & 15) == 0;
+    const bool vec = cin_dout_vec(A, N, D, dOut, dh, dd);
+    const int gx = ceil_div(N, vec ? 4096 : 1024);
     if (vec)
-        hipLaunchKernelGGL(cin_dout_kernel<4>, dim3(ceil_div(N, 4096), H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
-                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias);
+        hipLaunchKernelGGL(cin_dout_kernel<4>, dim3(gx, H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
+                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws);
     else
-        hipLaunchKernelGGL(cin_dout_kernel<1>, dim3(ceil_div(N, 1024), H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
-                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias);
+        hipLaunchKernelGGL(cin_dout_kernel<1>, dim3(gx, H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
+                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws);
+    if (ws) hipLaunchKernelGGL(cin_dbias_finish_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, (hipStream_t)stream, ws, H, gx, dbias);
     return xdfm_check_launch("cin_dout");
 }
 

@@ -36,6 +36,9 @@ SIGNATURES = {
     "xdfm_cin_direct_sum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_long, c_int, P]),
     "xdfm_cin_dout": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int,
                               c_int, P, P, P]),
+    "xdfm_cin_dout_ws_elems": (c_size_t, [c_int, c_int, c_int]),
+    "xdfm_cin_dout_det": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int,
+                                  c_int, P, P, P, P]),
     "xdfm_cin_bwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "xdfm_cin_level_bwd_x": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
@@ -55,6 +58,7 @@ SIGNATURES = {
     "xdfm_adam_step_lr": (c_int, [P, c_int, c_double, P, c_double, c_double, c_double, P, P, P]),
     "xdfm_adam_step_deferred": (c_int, [P, c_int, P, c_double, P, c_double, c_double, c_double, P, P, P]),
     "xdfm_adam_catchup_rows": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, P, P, c_double, c_double, c_double, P, P, P]),
+    "xdfm_adam_apply_rows": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, P, P, c_double, c_double, c_double, P, P, P]),
     "xdfm_adam_flush_ws_elems": (c_size_t, [c_int]),
     "xdfm_adam_flush": (c_int, [P, c_int, P, c_double, c_double, c_double, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
@@ -83,7 +87,8 @@ class AdamClock(ctypes.Structure):
 
 class AdamRows(ctypes.Structure):
     """xdfm_adam_rows of include/xdfm.h (device pointer tables of one gather's fields)"""
-    _fields_ = [("param", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("last", c_void_p), ("l2", c_void_p)]
+    _fields_ = [("param", c_void_p), ("exp_avg", c_void_p), ("exp_avg_sq", c_void_p), ("last", c_void_p), ("l2", c_void_p),
+                ("grad", c_void_p), ("marks", c_void_p)]
 
 
 ABI_VERSION = 6

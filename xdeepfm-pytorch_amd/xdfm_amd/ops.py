@@ -427,10 +427,11 @@ class CINStack(torch.autograd.Function):
             dOut = torch.empty((H, N), dtype=torch.float32, device=dev)
             dbias = dbias_all[dbias_off[l]:dbias_off[l] + H]
             has_hid = dhid is not None and hid > 0
-            _lib.check(lib.xdfm_cin_dout(_ptr(A), H, B, D, act, _ptr(dhid) if has_hid else None, 0,
-                                         hid if has_hid else 0, _ptr(g), 0 if pool == "sum" else 1,
-                                         fm if pool == "sum" else N, off, dir0, drows, _ptr(dOut), _ptr(dbias),
-                                         _stream()), "cin_dout")
+            dws = torch.empty(lib.xdfm_cin_dout_ws_elems(H, B, D), dtype=torch.float32, device=dev)   # fixed-order dbias
+            _lib.check(lib.xdfm_cin_dout_det(_ptr(A), H, B, D, act, _ptr(dhid) if has_hid else None, 0,
+                                             hid if has_hid else 0, _ptr(g), 0 if pool == "sum" else 1,
+                                             fm if pool == "sum" else N, off, dir0, drows, _ptr(dOut), _ptr(dbias),
+                                             _ptr(dws), _stream()), "cin_dout")
             if ctx.needs_input_grad[7 + 2 * l]:
                 ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m, N), dtype=torch.float32, device=dev)
                 dW = torch.empty((H, Hp * m), dtype=torch.float32, device=dev)

@@ -109,6 +109,45 @@ class TableAdam(torch.optim.Adam):
             self.generation += 1                       # a step captured without the catch-up launch is stale
         return self._def
 
+    def _rows_for_apply(self, d, params, grads, arr, deferred_now):
+        """(plan, X, emb rows, lin rows, indices of the tensors K7 still sweeps) when the step's update of the deferred
+        tables can be keyed by the batch of the one gather that fed them -- a single process, one gather, every deferred
+        table among its fields -- else None (the mark bytes are scanned)."""
+        from . import dist as xdist
+        g = d.get("gather")
+        if g is None or xdist.current() is not None or len(d["plans"]) != 1 or os.environ.get("XDFM_ADAM_ROWS", "1") == "0":
+            return None
+        plan, X, emb_tables, lin_tables = g
+        index = {params[k].data_ptr(): k for k in deferred_now}
+        fields = list(emb_tables) + list(lin_tables)
+        if len(fields) != len(index) or any(t.data_ptr() not in index for t in fields) or X.shape[0] <= 0:
+            return None
+        key = ("apply", tuple(t.data_ptr() for t in fields), tuple(grads[index[t.data_ptr()]].data_ptr() for t in fields))
+        hit = d["rows"].get(key)
+        if hit is None:
+            dev = X.device
+            mk = lambda vals: torch.tensor(vals, dtype=torch.int64, device=dev)
+
+            def table_of(ts):
+                if not ts:
+                    return None, None
+                ent = [d["tensors"][t.data_ptr()] for t in ts]
+                ks = [index[t.data_ptr()] for t in ts]
+                arrs = (mk([t.data_ptr() for t in ts]), mk([e[0].data_ptr() for e in ent]), mk([e[1].data_ptr() for e in ent]),
+                        mk([e[2].data_ptr() for e in ent]), torch.tensor([e[3] for e in ent], dtype=torch.float32, device=dev),
+                        mk([grads[k].data_ptr() for k in ks]), mk([arr[k].grad_marks for k in ks]))
+                return _lib.AdamRows(*[a.data_ptr() for a in arrs]), arrs
+            e_struct, e_keep = table_of(list(emb_tables))
+            l_struct, l_keep = table_of(list(lin_tables))
+            hit = d["rows"][key] = (e_struct, l_struct, e_keep, l_keep)
+        if "cell" not in d:
+            d["cell"] = torch.zeros(1, dtype=torch.int64, device=X.device)
+        deferred = set(deferred_now)
+        rest = [k for k in range(len(params)) if k not in deferred]
+        if not rest:
+            return None
+        return plan, X, hit[0], hit[1], rest
+
     def _last_bytes(self, p):
         d = self._def
         key = p.data_ptr()
@@ -120,7 +159,10 @@ class TableAdam(torch.optim.Adam):
     def _catchup(self, plan, X, emb_tables, lin_tables):
         """Called by the gather (ops.EmbedGather.forward) before it reads the rows of X."""
         d = self._def
-        if d is None or (self._since == 0 and not torch.cuda.is_current_stream_capturing()):
+        if d is None:
+            return
+        d["gather"] = (plan, X, tuple(emb_tables), tuple(lin_tables))      # the step's update is keyed by the same rows
+        if self._since == 0 and not torch.cuda.is_current_stream_capturing():
             return
         key = (tuple(t.data_ptr() for t in emb_tables), tuple(t.data_ptr() for t in lin_tables))
         rows = d["rows"].get(key)
@@ -135,7 +177,7 @@ class TableAdam(torch.optim.Adam):
                 mk = lambda vals: torch.tensor(vals, dtype=torch.int64, device=dev)
                 arrs = (mk([t.data_ptr() for t in ts]), mk([e[0].data_ptr() for e in ent]), mk([e[1].data_ptr() for e in ent]),
                         mk([e[2].data_ptr() for e in ent]), torch.tensor([e[3] for e in ent], dtype=torch.float32, device=dev))
-                return _lib.AdamRows(*[a.data_ptr() for a in arrs]), arrs
+                return _lib.AdamRows(*([a.data_ptr() for a in arrs] + [None, None])), arrs
             e_struct, e_keep = table_of(emb_tables)
             l_struct, l_keep = table_of(lin_tables)
             rows = d["rows"][key] = (e_struct, l_struct, e_keep, l_keep)
@@ -338,11 +380,35 @@ class TableAdam(torch.optim.Adam):
             from . import ops                          # per-kernel timing hook of bench.py (HIP events on the launch stream)
             nbytes = sum(params[k].numel() * (0.0625 if arr[k].flags == 2 else (24.25 if arr[k].grad_marks else 28.0)) for k in range(T))
             if deferred_now and d is not None:
-                _lib.check(ops._run("adam_step[bytes]", nbytes, lambda: lib.xdfm_adam_step_deferred(
-                    ctypes.cast(arr, ctypes.c_void_p), T, ctypes.byref(d["clk"]), float(group["lr"]),
-                    lr_dev[1].data_ptr() if lr_dev is not None else None, float(beta1), float(beta2), float(group["eps"]),
-                    ws.data_ptr() if ws is not None else None, val.data_ptr() if val is not None else None, stream)),
-                    "adam_step_deferred")
+                by_rows = self._rows_for_apply(d, params, grads, arr, deferred_now)
+                if by_rows is None:
+                    # the mark bytes say which chunks have a gradient (row-parallel runs: rows of every rank)
+                    _lib.check(ops._run("adam_step[bytes]", nbytes, lambda: lib.xdfm_adam_step_deferred(
+                        ctypes.cast(arr, ctypes.c_void_p), T, ctypes.byref(d["clk"]), float(group["lr"]),
+                        lr_dev[1].data_ptr() if lr_dev is not None else None, float(beta1), float(beta2), float(group["eps"]),
+                        ws.data_ptr() if ws is not None else None, val.data_ptr() if val is not None else None, stream)),
+                        "adam_step_deferred")
+                else:
+                    # single process: the chunks with a gradient are the rows of the batch -- no scan of the mark bytes
+                    plan, X, e_struct, l_struct, rest = by_rows
+                    arr2 = (_lib.AdamTensor * max(len(rest), 1))()
+                    for j, k in enumerate(rest):
+                        ctypes.memmove(ctypes.byref(arr2[j]), ctypes.byref(arr[k]), ctypes.sizeof(_lib.AdamTensor))
+                    cols, vocab, _, _ = plan.on(X.device)
+
+                    def launch():
+                        rc = lib.xdfm_adam_step_deferred(
+                            ctypes.cast(arr2, ctypes.c_void_p), len(rest), ctypes.byref(d["clk"]), float(group["lr"]),
+                            lr_dev[1].data_ptr() if lr_dev is not None else None, float(beta1), float(beta2), float(group["eps"]),
+                            ws.data_ptr() if ws is not None else None, val.data_ptr() if val is not None else None, stream)
+                        if rc:
+                            return rc
+                        return lib.xdfm_adam_apply_rows(
+                            X.data_ptr(), X.stride(0), X.shape[0], cols.data_ptr(), vocab.data_ptr(), plan.m, plan.D,
+                            ctypes.byref(e_struct), ctypes.byref(l_struct) if l_struct is not None else None, ctypes.byref(d["clk"]),
+                            float(beta1), float(beta2), float(group["eps"]), d["cell"].data_ptr(),
+                            val.data_ptr() if val is not None else None, stream)
+                    _lib.check(ops._run("adam_step[bytes]", nbytes, launch), "adam_step_deferred (rows)")
                 if not capturing:
                     self._since += 1
             else:
