@@ -297,8 +297,15 @@ def _big_vocab_model(dev, deferred, use_graph, flush_every=5, emb_dim=D):
     return model, step, vocab
 
 
+def test_deferred_table_update_keyed_by_the_batch_rows_is_bit_identical_too(monkeypatch):
+    """The opt-in variant of the step's table update (XDFM_ADAM_ROWS=1): chunks with a gradient are enumerated from the
+    batch's rows instead of by scanning the mark bytes (xdfm_adam_apply_rows)."""
+    monkeypatch.setenv("XDFM_ADAM_ROWS", "1")
+    test_deferred_table_update_is_bit_identical_to_the_dense_sweep(True, 10, expect_path="rows")
+
+
 @pytest.mark.parametrize("use_graph,emb_dim", [(False, D), (True, D), (True, 10)], ids=["eager", "graph", "graph-D10"])
-def test_deferred_table_update_is_bit_identical_to_the_dense_sweep(use_graph, emb_dim):
+def test_deferred_table_update_is_bit_identical_to_the_dense_sweep(use_graph, emb_dim, expect_path="scan"):
     """K7d (include/xdfm.h): rows are updated when gathered / when a gradient arrives / every `flush_every` steps instead
     of every step.  Parameters, both moments and the step counters must equal the dense sweep's BIT FOR BIT -- after 23
     steps with cold and hot rows, a learning-rate change, a prediction in the middle (flush), flushes at steps that are
@@ -333,6 +340,7 @@ def test_deferred_table_update_is_bit_identical_to_the_dense_sweep(use_graph, em
     m_d, st_d, sd_d, mo_d, tot_d, pred_d = run(False)
     m_l, st_l, sd_l, mo_l, tot_l, pred_l = run(True)
     assert m_l.optim._def is not None and m_d.optim._def is None
+    assert m_l.optim.path_counts[expect_path] >= 2 and len(m_l.optim._def["tensors"]) == 12      # 6 embedding + 6 linear tables
     if use_graph:
         assert st_l.replays >= 15 and not st_l.disabled
     assert torch.equal(pred_d, pred_l)

@@ -76,6 +76,7 @@ class EmbedPlan:
         self.arena_on = False     # the model's train step sets this when its optimizer consumes marked gradients
         self._arenas = {}
         self.catchup = None       # set by optim.TableAdam (deferred update): brings the rows of X up to date before they are read
+        self.last_gather = None   # (X, embedding tables, linear tables) of the latest gather: the rows a deferred update is keyed by
 
     def on(self, device):
         key = str(device)
@@ -197,6 +198,7 @@ class EmbedGather(torch.autograd.Function):
         emb_fm = torch.empty((m, B * D), dtype=torch.float32, device=X.device)
         dnn_in = torch.empty((B, m * D + nd), dtype=torch.float32, device=X.device)
         lin = torch.empty((B, 1), dtype=torch.float32, device=X.device)
+        plan.last_gather = (X, tuple(emb_tables), tuple(lin_tables))
         if plan.catchup is not None:
             plan.catchup(plan, X, emb_tables, lin_tables)
         tp = plan.pointer_table(emb_tables, "emb")

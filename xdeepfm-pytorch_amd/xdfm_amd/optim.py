@@ -34,6 +34,7 @@ class TableAdam(torch.optim.Adam):
         self.flush_every = max(1, min(int(flush_every), DEFER_CAP - 8))
         self._def = None            # clock, constants, per-table `last` bytes, backlog (built by the first deferred step)
         self._since = 0             # steps since the last flush (host count of what the device clock holds)
+        self.path_counts = {"rows": 0, "scan": 0}      # deferred steps issued (or captured) by path: keyed by the batch's rows / by the mark bytes
         # OPT-IN deviation from the reference: rows of the embedding tables that a batch does not touch
         # are not updated at all (no moment decay, no L2 pull) -- "lazy" Adam.  The reference's dense Adam updates every
         # row every step; with `lazy_rows` the step's cost follows the batch instead of the vocabulary.  Applies only to
@@ -114,10 +115,15 @@ class TableAdam(torch.optim.Adam):
         tables can be keyed by the batch of the one gather that fed them -- a single process, one gather, every deferred
         table among its fields -- else None (the mark bytes are scanned)."""
         from . import dist as xdist
-        g = d.get("gather")
-        if g is None or xdist.current() is not None or len(d["plans"]) != 1 or os.environ.get("XDFM_ADAM_ROWS", "1") == "0":
+        # Opt-in (XDFM_ADAM_ROWS=1): with skewed ids the rows path is SLOWER than the scan of the mark bytes -- a hot id
+        # occurs hundreds of times in a batch and every occurrence contends for the claim of the same `last` word
+        # (0.36 ms against 0.18 ms per step at the Criteo-card benchmark); it pays for batches of mostly distinct ids.
+        if xdist.current() is not None or len(d["plans"]) != 1 or os.environ.get("XDFM_ADAM_ROWS", "0") != "1":
             return None
-        plan, X, emb_tables, lin_tables = g
+        plan = d["plans"][0]
+        if plan.last_gather is None:
+            return None
+        X, emb_tables, lin_tables = plan.last_gather
         index = {params[k].data_ptr(): k for k in deferred_now}
         fields = list(emb_tables) + list(lin_tables)
         if len(fields) != len(index) or any(t.data_ptr() not in index for t in fields) or X.shape[0] <= 0:
@@ -161,7 +167,6 @@ class TableAdam(torch.optim.Adam):
         d = self._def
         if d is None:
             return
-        d["gather"] = (plan, X, tuple(emb_tables), tuple(lin_tables))      # the step's update is keyed by the same rows
         if self._since == 0 and not torch.cuda.is_current_stream_capturing():
             return
         key = (tuple(t.data_ptr() for t in emb_tables), tuple(t.data_ptr() for t in lin_tables))
@@ -329,6 +334,13 @@ class TableAdam(torch.optim.Adam):
             # row-parallel runs included: a rank's own rows are brought up to date before its gather, the rows the other
             # ranks touched arrive with their marks and are replayed inside the step -- every replica ends with the same bits
             defer_ok = self.deferred and not self.lazy_rows and gi == 0
+            # the tables of the gathers that feed this optimizer (their rows are what a batch touches)
+            table_ptrs = set()
+            for src in self.grad_sources:
+                lg = getattr(src, "last_gather", None)
+                if lg is not None:
+                    table_ptrs.update(t.data_ptr() for t in lg[1])
+                    table_ptrs.update(t.data_ptr() for t in lg[2])
             deferred_now = []
             for k in range(T):
                 gp = grads[k].data_ptr()
@@ -339,7 +351,7 @@ class TableAdam(torch.optim.Adam):
                         arr[k].grad_marks = mp
                         table = params[k].dim() == 2 and params[k].shape[0] > 1
                         arr[k].flags = 1 if (self.lazy_rows and table) else 0
-                        if defer_ok and table:
+                        if defer_ok and params[k].data_ptr() in table_ptrs:
                             deferred_now.append(k)
                         a.consumed(gp)
                         break
@@ -381,6 +393,7 @@ class TableAdam(torch.optim.Adam):
             nbytes = sum(params[k].numel() * (0.0625 if arr[k].flags == 2 else (24.25 if arr[k].grad_marks else 28.0)) for k in range(T))
             if deferred_now and d is not None:
                 by_rows = self._rows_for_apply(d, params, grads, arr, deferred_now)
+                self.__dict__.setdefault("path_counts", {"rows": 0, "scan": 0})["rows" if by_rows is not None else "scan"] += 1
                 if by_rows is None:
                     # the mark bytes say which chunks have a gradient (row-parallel runs: rows of every rank)
                     _lib.check(ops._run("adam_step[bytes]", nbytes, lambda: lib.xdfm_adam_step_deferred(
