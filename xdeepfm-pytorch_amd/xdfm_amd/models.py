@@ -544,6 +544,7 @@ class BaseModel(nn.Module):
     def compile(self, optimizer, loss=None, metrics=None):
         self.metrics_names = ["loss"]
         self._optim_capturable = False
+        self._flush_optim()                # a previous optimizer may still owe table rows their latest steps
         self.optim = self._get_optim(optimizer)
         from .optim import TableAdam
         if isinstance(self.optim, TableAdam):          # also when handed in as an object, e.g. TableAdam(..., lazy_rows=True)
