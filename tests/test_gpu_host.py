@@ -384,3 +384,40 @@ def test_deferred_table_update_fit_history_and_checkpoint_match_the_dense_sweep(
     for k in sd_d:
         assert torch.equal(sd_d[k], sd_l[k]), k
         assert torch.equal(sd2_d[k], sd2_l[k]), "after a user-driven step: " + k
+
+
+def test_deferred_table_update_soak_400_replayed_steps_with_the_default_period():
+    """400 graph-replayed steps at the default flush period (32) on tables of 100 k rows (most rows are never touched, hot
+    rows every step), ragged last batches of an 'epoch' every 50 steps, then bit-equality with the dense sweep."""
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr.models import xDeepFM
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    vocab = [100000, 57, 100003, 1000, 9, 31337]
+
+    def run(deferred):
+        cols = [SparseFeat("C%d" % (i + 1), v, 16) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(ND)]
+        torch.manual_seed(8)
+        model = xDeepFM(cols, cols, dnn_hidden_units=(32, 16), cin_layer_size=(16, 8), l2_reg_dnn=1e-5, device=dev)
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if "embedding_dict" in k:
+                    p.mul_(2000.0)
+        model.compile("adam", "binary_crossentropy", metrics=[])
+        model.optim.deferred = bool(deferred)
+        model.train()
+        for s in range(400):
+            rows = 100 if s % 50 == 49 else 512
+            X, y = orc.synthetic_batch(rows, vocab, ND, seed=9000 + s)
+            model.train_on_batch(T(X).to(dev), T(y).to(dev))
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        mo = [(model.optim.state[p]["exp_avg"].clone(), model.optim.state[p]["exp_avg_sq"].clone()) for p in model.optim.param_groups[0]["params"]]
+        return model, sd, mo
+
+    m_d, sd_d, mo_d = run(False)
+    m_l, sd_l, mo_l = run(True)
+    assert m_l.optim._def is not None and m_l.__dict__["_graphed_step"].replays >= 300
+    for k in sd_d:
+        assert torch.equal(sd_d[k], sd_l[k]), k
+    for (a, b), (c, d) in zip(mo_d, mo_l):
+        assert torch.equal(a, c) and torch.equal(b, d)
