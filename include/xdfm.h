@@ -368,10 +368,11 @@ typedef struct {
     unsigned char* const* marks;
 } xdfm_adam_rows;
 /* Brings the rows a batch is about to gather (X, cols, vocab as in xdfm_embed_gather_fwd; lin may be NULL) up to the
- * clock.  ws: xdfm_adam_flush_ws_elems(0) floats.  backlog[0] += L2 value of the replayed steps. */
+ * clock.  backlog: one 64-bit device cell (8-byte aligned, zeroed once by the caller); the L2 value of the replayed
+ * steps is ADDED to it in 2^-40 fixed point (integer adds: the total does not depend on the order of the threads). */
 int xdfm_adam_catchup_rows(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
                            const xdfm_adam_rows* emb, const xdfm_adam_rows* lin, const xdfm_adam_clock* clk,
-                           double beta1, double beta2, double eps, float* ws, float* backlog, void* stream);
+                           double beta1, double beta2, double eps, float* backlog, void* stream);
 /* The step's update of the deferred tables, keyed by the batch instead of by a scan of the mark bytes: for the rows of X
  * (the batch whose gradients the scatter just wrote: single process), apply step clock[0] -- to be called after
  * xdfm_adam_step_deferred over the OTHER tensors, which advances the clock.  Reads the rows' gradient chunks, zeroes
@@ -382,9 +383,8 @@ int xdfm_adam_apply_rows(const float* X, long ldx, int B, const int* cols, const
                          double beta1, double beta2, double eps, float* l2_cell, float* l2_value, void* stream);
 /* Brings every chunk of the XDFM_ADAM_DEFERRED tensors up to the clock, then resets the clock (clock[1] += clock[0],
  * clock[0] = 0, every `last` byte 0). */
-size_t xdfm_adam_flush_ws_elems(int T);
 int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double beta1, double beta2,
-                    double eps, float* ws, float* backlog, void* stream);
+                    double eps, float* backlog, void* stream);
 
 #ifdef __cplusplus
 }

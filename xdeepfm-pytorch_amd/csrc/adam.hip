@@ -632,12 +632,9 @@ static int adam_step_impl(const xdfm_adam_tensor* tensors, int T, const xdfm_ada
     return xdfm_check_launch("adam_step");
 }
 
-size_t xdfm_adam_flush_ws_elems(int T) { (void)T; return 4; }    // the backlog accumulator itself: one 64-bit fixed-point cell
-
 int xdfm_adam_catchup_rows(const float* X, long ldx, int B, const int* cols, const int* vocab, int m, int D,
                            const xdfm_adam_rows* emb, const xdfm_adam_rows* lin, const xdfm_adam_clock* clk,
-                           double beta1, double beta2, double eps, float* ws, float* backlog, void* stream) {
-    (void)ws;
+                           double beta1, double beta2, double eps, float* backlog, void* stream) {
     XDFM_REQUIRE(X && cols && vocab && emb && clk && backlog, "adam_catchup_rows: null pointer");
     XDFM_REQUIRE(B > 0 && m > 0 && D > 0, "adam_catchup_rows: bad shape B=%d m=%d D=%d", B, m, D);
     XDFM_REQUIRE((((size_t)backlog) & 7) == 0, "adam_catchup_rows: backlog must be 8-byte aligned");
@@ -671,8 +668,7 @@ int xdfm_adam_apply_rows(const float* X, long ldx, int B, const int* cols, const
 }
 
 int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double beta1, double beta2,
-                    double eps, float* ws, float* backlog, void* stream) {
-    (void)ws;
+                    double eps, float* backlog, void* stream) {
     XDFM_REQUIRE(tensors && clk && clk->clock && clk->consts && backlog, "adam_flush: null pointer");
     XDFM_REQUIRE((((size_t)backlog) & 7) == 0, "adam_flush: backlog must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;

@@ -57,10 +57,9 @@ SIGNATURES = {
     "xdfm_adam_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, P, P, P]),
     "xdfm_adam_step_lr": (c_int, [P, c_int, c_double, P, c_double, c_double, c_double, P, P, P]),
     "xdfm_adam_step_deferred": (c_int, [P, c_int, P, c_double, P, c_double, c_double, c_double, P, P, P]),
-    "xdfm_adam_catchup_rows": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, P, P, c_double, c_double, c_double, P, P, P]),
+    "xdfm_adam_catchup_rows": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, P, P, c_double, c_double, c_double, P, P]),
     "xdfm_adam_apply_rows": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, P, P, c_double, c_double, c_double, P, P, P]),
-    "xdfm_adam_flush_ws_elems": (c_size_t, [c_int]),
-    "xdfm_adam_flush": (c_int, [P, c_int, P, c_double, c_double, c_double, P, P, P]),
+    "xdfm_adam_flush": (c_int, [P, c_int, P, c_double, c_double, c_double, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
     "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
     "xdfm_relu_bwd_colsum": (c_int, [P, P, c_long, c_int, c_long, c_long, P, P, P, P]),

@@ -196,7 +196,7 @@ class TableAdam(torch.optim.Adam):
         _lib.check(lib.xdfm_adam_catchup_rows(
             X.data_ptr(), X.stride(0), X.shape[0], cols.data_ptr(), vocab.data_ptr(), plan.m, plan.D, ctypes.byref(e_struct),
             ctypes.byref(l_struct) if l_struct is not None else None, ctypes.byref(d["clk"]), float(beta1), float(beta2),
-            float(group["eps"]), None, d["backlog"].data_ptr(), torch.cuda.current_stream(X.device).cuda_stream),
+            float(group["eps"]), d["backlog"].data_ptr(), torch.cuda.current_stream(X.device).cuda_stream),
             "adam_catchup_rows")
 
     @torch.no_grad()
@@ -217,7 +217,7 @@ class TableAdam(torch.optim.Adam):
             beta1, beta2 = group["betas"]
             dev = d["clock"].device
             _lib.check(_lib.load().xdfm_adam_flush(ctypes.cast(arr, ctypes.c_void_p), len(ent), ctypes.byref(d["clk"]), float(beta1),
-                                                   float(beta2), float(group["eps"]), None, d["backlog"].data_ptr(),
+                                                   float(beta2), float(group["eps"]), d["backlog"].data_ptr(),
                                                    torch.cuda.current_stream(dev).cuda_stream), "adam_flush")
         self._since = 0
 
