@@ -11,11 +11,14 @@ import numpy as np
 import torch
 from bench import WORKLOADS, build_model, synthetic_batches
 
-rows = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
-bs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+nums = [a for a in sys.argv[1:] if a.isdigit()]
+rows = int(nums[0]) if len(nums) > 0 else 262144
+bs = int(nums[1]) if len(nums) > 1 else 4096
 cfg = WORKLOADS["criteo_c2"]
-model = build_model(cfg, 100000, torch.device("cuda:0"))
-(X, y), = synthetic_batches(1, rows, [100000] * cfg["n_sparse"], cfg["n_dense"], seed=1)
+card = "card" in sys.argv
+vocab = list(__import__("bench").CRITEO_CARD) if card else [100000] * cfg["n_sparse"]
+model = build_model(cfg, vocab, torch.device("cuda:0"))
+(X, y), = synthetic_batches(1, rows, vocab, cfg["n_dense"], seed=1)
 names = list(model.feature_index.keys())
 xs = {n: X[:, i] for i, n in enumerate(names)}
 model.fit(xs, y, batch_size=bs, epochs=1, verbose=0)            # warm-up epoch (allocator, first launches)
