@@ -1,6 +1,5 @@
 """K7 alone on Criteo-card-sized tables: GB/s of the 24.25 B per parameter for grid caps (library option adam_bx) and
 cached vs non-temporal accesses (dbg bit 17).   python tools/adam_probe.py [mid]"""
-import ctypes
 import os
 import sys
 

@@ -7,7 +7,6 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "xdeepfm-pytorch_amd"))
 sys.path.insert(0, ROOT)
-import numpy as np
 import torch
 from bench import WORKLOADS, build_model, synthetic_batches
 
