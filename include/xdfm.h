@@ -386,6 +386,15 @@ int xdfm_adam_apply_rows(const float* X, long ldx, int B, const int* cols, const
 int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double beta1, double beta2,
                     double eps, float* backlog, void* stream);
 
+/* ------------------------------------------------------------------ SFG heads of xdeepfm_pro: tiled vocabulary CE
+ * replaces: the elementwise / reduction chains around the tile GEMMs of nn.Linear(K, V) + F.cross_entropy
+ *           (deepctr/xdeepfm_pro/sfg_decoder.py:146-149, :277-283) when the vocabulary is walked in tiles.
+ * z [rows][ld]: the logits of one vocabulary tile (T columns).  lse_update: (m[r], s[r]) <- online log-sum-exp of
+ * (m[r], s[r]) and the row's T logits (m = -inf, s = 0 before the first tile).  softmax_grad: z <- exp(z - lse[r]) * g[r]
+ * in place. */
+int xdfm_vocab_lse_update(const float* z, long ld, int rows, int T, float* m, float* s, void* stream);
+int xdfm_vocab_softmax_grad(float* z, long ld, int rows, int T, const float* lse, const float* g, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

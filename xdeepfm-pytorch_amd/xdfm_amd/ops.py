@@ -740,11 +740,13 @@ class VocabSoftmaxCE(torch.autograd.Function):
         T = VocabSoftmaxCE._tile(rows, V)
         m = torch.full((rows,), float("-inf"), dtype=torch.float32, device=hidden.device)
         ssum = torch.zeros(rows, dtype=torch.float32, device=hidden.device)
+        lib = _lib.load()
         for v0 in range(0, V, T):
             z = torch.addmm(b[v0:v0 + T], hidden, W[v0:v0 + T].t())
-            m_new = torch.maximum(m, z.max(dim=1).values)
-            ssum = ssum * torch.exp(m - m_new) + torch.exp(z - m_new[:, None]).sum(dim=1)
-            m = m_new
+            # one read of the tile: row maxima, then sum of exp against the running maximum (m, ssum updated in place)
+            if rows > 0:
+                _lib.check(lib.xdfm_vocab_lse_update(_ptr(z), z.stride(0), rows, z.shape[1], _ptr(m), _ptr(ssum), _stream()),
+                           "vocab_lse_update")
         lse = m + torch.log(ssum)
         zt = (hidden * W.index_select(0, tgt)).sum(dim=1) + b.index_select(0, tgt)
         ctx.save_for_backward(hidden, W, b, tgt, lse)
@@ -760,8 +762,10 @@ class VocabSoftmaxCE(torch.autograd.Function):
         db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
         dh = torch.zeros_like(hidden) if ctx.needs_input_grad[0] else None
         for v0 in range(0, V, T):
-            z = torch.addmm(b[v0:v0 + T], hidden, W[v0:v0 + T].t())
-            dz = torch.exp(z - lse[:, None]) * g[:, None]                # g * softmax
+            dz = torch.addmm(b[v0:v0 + T], hidden, W[v0:v0 + T].t())
+            if rows > 0:                                                 # g * softmax, in place
+                _lib.check(_lib.load().xdfm_vocab_softmax_grad(_ptr(dz), dz.stride(0), rows, dz.shape[1], _ptr(lse), _ptr(g),
+                                                               _stream()), "vocab_softmax_grad")
             if dW is not None:
                 torch.mm(dz.t(), hidden, out=dW[v0:v0 + T])
             if db is not None:
