@@ -24,14 +24,14 @@ DEFER_CAP = 256          # steps the clock's constant table holds (the `last` by
 
 
 class TableAdam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lazy_rows=False, deferred=None, flush_every=32):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, lazy_rows=False, deferred=None, flush_every=64):
         super().__init__(params, lr=lr, betas=betas, eps=eps, fused=True, capturable=True)
         # Deferred (exact) update of the tables, include/xdfm.h "K7d": same bits as the dense sweep, but a row is brought
         # up to date when a batch gathers it, when a gradient arrives for it, and every `flush_every` steps for all rows
         # -- the sweep's 24 bytes per table parameter are moved once per `flush_every` steps instead of every step.
         # Applies, like the marks, inside the model's own train step in a single process.  XDFM_ADAM_DEFERRED=0 turns it off.
         self.deferred = (os.environ.get("XDFM_ADAM_DEFERRED", "1") != "0") if deferred is None else bool(deferred)
-        self.flush_every = max(1, min(int(flush_every), DEFER_CAP - 8))
+        self.flush_every = max(1, min(int(os.environ.get("XDFM_ADAM_FLUSH_EVERY", flush_every)), DEFER_CAP - 8))
         self._def = None            # clock, constants, per-table `last` bytes, backlog (built by the first deferred step)
         self._since = 0             # steps since the last flush (host count of what the device clock holds)
         self.path_counts = {"rows": 0, "scan": 0}      # deferred steps issued (or captured) by path: keyed by the batch's rows / by the mark bytes
@@ -262,7 +262,7 @@ class TableAdam(torch.optim.Adam):
         self.__dict__.setdefault("grad_sources", [])
         self.__dict__.setdefault("lazy_rows", False)
         self.__dict__.setdefault("deferred", False)
-        self.__dict__.setdefault("flush_every", 32)
+        self.__dict__.setdefault("flush_every", 64)
         self.__dict__["_def"] = None
         self.__dict__["_since"] = 0
         self.generation = self.__dict__.get("generation", 0) + 1
