@@ -20,6 +20,8 @@ import torch.multiprocessing as mp
 from conftest import PKG, ROOT
 
 VOCAB, ND, D = [9, 6, 12, 5, 7], 2, 4
+if os.environ.get("XDFM_TEST_BIG_VOCAB") == "1":     # spawned workers re-import this module: the switch travels by environment
+    VOCAB = [3001, 6, 7013, 5, 502]
 CIN, DNN = (6, 4), (8,)
 
 
@@ -143,4 +145,22 @@ def test_row_parallel_fit_equals_single_process_gpu(tmp_path):
     # part of the row exchange with zero rows): from the third full batch on, each rank replays the collective-free
     # half of its step from a HIP graph and the single-process run replays its whole step
     replays = _check(tmp_path, "cuda:0", False, rtol=1e-3, atol=2e-5, n_rows=343)
+    assert min(replays) >= 2, replays
+
+
+@pytest.mark.gpu
+def test_row_parallel_four_ranks_with_cold_rows_gpu(tmp_path, monkeypatch):
+    """Four ranks on one GPU, vocabularies of thousands of rows (most rows cold, 16-row shards): the deferred table update
+    brings a rank's own rows up to date before its gather and replays, inside the step, the rows the other ranks touched;
+    replicas must stay bit-identical and follow the single-process run."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("XDFM_TEST_BIG_VOCAB", "1")
+    global VOCAB
+    old = VOCAB
+    VOCAB = [3001, 6, 7013, 5, 502]
+    try:
+        replays = _check(tmp_path, "cuda:0", False, rtol=1e-3, atol=2e-5, n_rows=409, world=4)
+    finally:
+        VOCAB = old
     assert min(replays) >= 2, replays
