@@ -298,9 +298,10 @@ def _big_vocab_model(dev, deferred, use_graph, flush_every=5, emb_dim=D):
 
 
 def test_deferred_table_update_keyed_by_the_batch_rows_is_bit_identical_too(monkeypatch):
-    """The opt-in variant of the step's table update (XDFM_ADAM_ROWS=1): chunks with a gradient are enumerated from the
-    batch's rows instead of by scanning the mark bytes (xdfm_adam_apply_rows)."""
-    monkeypatch.setenv("XDFM_ADAM_ROWS", "1")
+    """The step's update of the BIG tables (>= 1 M elements by default; lowered here): chunks with a gradient are enumerated
+    from the batch's rows instead of by scanning the mark bytes (xdfm_adam_apply_rows); small tables, where an id occurs
+    hundreds of times per batch, stay with the scan."""
+    monkeypatch.setenv("XDFM_ADAM_ROWS_MIN_NUMEL", "30000")      # the 5000- and 20003-row tables by rows, the small ones by the scan
     test_deferred_table_update_is_bit_identical_to_the_dense_sweep(True, 10, expect_path="rows")
 
 

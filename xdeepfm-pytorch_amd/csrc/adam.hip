@@ -452,7 +452,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
         const long c0 = id * w / 4, c1 = (id * w + w - 1) / 4;
         const long cc = c0 + (is_lin ? 0 : q);
         const long n4 = (long)V * w / 4;
-        if (cc <= c1 && cc < n4) {
+        if (cc <= c1 && cc < n4 && R.p[f] != nullptr) {         // a null table: left to the step's mark scan (small tables)
             unsigned char* last = R.last[f];
             unsigned* word = reinterpret_cast<unsigned*>(last + (cc & ~3L));
             const int sh = (int)(cc & 3) * 8;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
             const AdamRowsDev& R = is_lin ? lin : emb;
             const long numel = (long)vocab[f] * (is_lin ? 1 : D);
             const long e = numel / 4 * 4 + k;
-            if (e < numel) {
+            if (e < numel && R.p[f] != nullptr) {
                 float* p = R.p[f]; float* mm = R.m[f]; float* vv = R.v[f]; float* g = R.g[f];
                 const float l2c = R.l2[f];
                 float pa = p[e], ma = mm[e], va = vv[e];

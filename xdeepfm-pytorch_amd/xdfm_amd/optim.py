@@ -21,6 +21,7 @@ import torch
 from . import _lib
 
 DEFER_CAP = 256          # steps the clock's constant table holds (the `last` bytes count steps since the last flush)
+ROWS_MIN_NUMEL = 1 << 20  # tables at least this large get the step's update by the batch's rows (XDFM_ADAM_ROWS_MIN_NUMEL overrides)
 
 
 class TableAdam(torch.optim.Adam):
@@ -115,10 +116,10 @@ class TableAdam(torch.optim.Adam):
         tables can be keyed by the batch of the one gather that fed them -- a single process, one gather, every deferred
         table among its fields -- else None (the mark bytes are scanned)."""
         from . import dist as xdist
-        # Opt-in (XDFM_ADAM_ROWS=1): with skewed ids the rows path is SLOWER than the scan of the mark bytes -- a hot id
-        # occurs hundreds of times in a batch and every occurrence contends for the claim of the same `last` word
-        # (0.36 ms against 0.18 ms per step at the Criteo-card benchmark); it pays for batches of mostly distinct ids.
-        if xdist.current() is not None or len(d["plans"]) != 1 or os.environ.get("XDFM_ADAM_ROWS", "0") != "1":
+        # Big tables only (ROWS_MIN_NUMEL): in a small table an id occurs hundreds of times per batch and every occurrence
+        # contends for the claim of the same `last` word (all tables by rows: 0.36 ms per step at the Criteo-card
+        # benchmark against 0.18 ms for the scan); small tables stay with the step's mark scan, where they cost nothing.
+        if xdist.current() is not None or len(d["plans"]) != 1 or os.environ.get("XDFM_ADAM_ROWS", "1") == "0":
             return None
         plan = d["plans"][0]
         if plan.last_gather is None:
@@ -128,28 +129,35 @@ class TableAdam(torch.optim.Adam):
         fields = list(emb_tables) + list(lin_tables)
         if len(fields) != len(index) or any(t.data_ptr() not in index for t in fields) or X.shape[0] <= 0:
             return None
-        key = ("apply", tuple(t.data_ptr() for t in fields), tuple(grads[index[t.data_ptr()]].data_ptr() for t in fields))
+        min_numel = int(os.environ.get("XDFM_ADAM_ROWS_MIN_NUMEL", ROWS_MIN_NUMEL))
+        key = ("apply", min_numel, tuple(t.data_ptr() for t in fields), tuple(grads[index[t.data_ptr()]].data_ptr() for t in fields))
         hit = d["rows"].get(key)
         if hit is None:
             dev = X.device
             mk = lambda vals: torch.tensor(vals, dtype=torch.int64, device=dev)
+
+            by_rows_k = set()
 
             def table_of(ts):
                 if not ts:
                     return None, None
                 ent = [d["tensors"][t.data_ptr()] for t in ts]
                 ks = [index[t.data_ptr()] for t in ts]
-                arrs = (mk([t.data_ptr() for t in ts]), mk([e[0].data_ptr() for e in ent]), mk([e[1].data_ptr() for e in ent]),
-                        mk([e[2].data_ptr() for e in ent]), torch.tensor([e[3] for e in ent], dtype=torch.float32, device=dev),
+                big = [t.numel() >= min_numel for t in ts]
+                by_rows_k.update(k for k, b in zip(ks, big) if b)
+                arrs = (mk([t.data_ptr() if b else 0 for t, b in zip(ts, big)]), mk([e[0].data_ptr() for e in ent]),
+                        mk([e[1].data_ptr() for e in ent]), mk([e[2].data_ptr() for e in ent]),
+                        torch.tensor([e[3] for e in ent], dtype=torch.float32, device=dev),
                         mk([grads[k].data_ptr() for k in ks]), mk([arr[k].grad_marks for k in ks]))
                 return _lib.AdamRows(*[a.data_ptr() for a in arrs]), arrs
             e_struct, e_keep = table_of(list(emb_tables))
             l_struct, l_keep = table_of(list(lin_tables))
-            hit = d["rows"][key] = (e_struct, l_struct, e_keep, l_keep)
+            hit = d["rows"][key] = (e_struct, l_struct, e_keep, l_keep, frozenset(by_rows_k))
         if "cell" not in d:
             d["cell"] = torch.zeros(1, dtype=torch.int64, device=X.device)
-        deferred = set(deferred_now)
-        rest = [k for k in range(len(params)) if k not in deferred]
+        if not hit[4]:
+            return None                                 # no table is big enough: everything by the scan
+        rest = [k for k in range(len(params)) if k not in hit[4]]      # K7 proper: dense tensors + the small deferred tables
         if not rest:
             return None
         return plan, X, hit[0], hit[1], rest
