@@ -392,7 +392,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_catchup_rows_kernel(
             unsigned* word = reinterpret_cast<unsigned*>(last + (cc & ~3L));
             const int sh = (int)(cc & 3) * 8;
             int old = -1;
-            unsigned seen = __atomic_load_n(word, __ATOMIC_RELAXED);
+            unsigned seen = *word;          // a plain (cached) read: stale at worst, and then the CAS below returns the current word
             while (true) {
                 const int ob = (int)((seen >> sh) & 255u);
                 if (ob >= t) break;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
             unsigned* word = reinterpret_cast<unsigned*>(last + (cc & ~3L));
             const int sh = (int)(cc & 3) * 8;
             int old = -1;
-            unsigned seen = __atomic_load_n(word, __ATOMIC_RELAXED);
+            unsigned seen = *word;          // a plain (cached) read: stale at worst, and then the CAS below returns the current word
             while (true) {
                 const int ob = (int)((seen >> sh) & 255u);
                 if (ob >= t) break;
