@@ -112,9 +112,10 @@ class TableAdam(torch.optim.Adam):
         return self._def
 
     def _rows_for_apply(self, d, params, grads, arr, deferred_now):
-        """(plan, X, emb rows, lin rows, indices of the tensors K7 still sweeps) when the step's update of the deferred
-        tables can be keyed by the batch of the one gather that fed them -- a single process, one gather, every deferred
-        table among its fields -- else None (the mark bytes are scanned)."""
+        """(plan, X, emb rows, lin rows, indices of the tensors K7 proper still handles) when the step's update of the BIG
+        deferred tables can be keyed by the batch of the one gather that feeds them -- a single process, one gather whose
+        fields are exactly the deferred tables, at least one table of ROWS_MIN_NUMEL elements -- else None (every deferred
+        table is updated by the scan of its mark bytes)."""
         from . import dist as xdist
         # Big tables only (ROWS_MIN_NUMEL): in a small table an id occurs hundreds of times per batch and every occurrence
         # contends for the claim of the same `last` word (all tables by rows: 0.36 ms per step at the Criteo-card
