@@ -25,6 +25,15 @@ if os.environ.get("XDFM_TEST_BIG_VOCAB") == "1":     # spawned workers re-import
 CIN, DNN = (6, 4), (8,)
 
 
+
+def _needs_default_env(feature):
+    """Tests that assert a feature is ACTIVE skip when the environment switches it off (XDFM_GRAD_ARENA=0 / XDFM_HIP_GRAPH=0 /
+    XDFM_ADAM_DEFERRED=0 are supported ways to run the product; the rest of the suite passes under them)."""
+    import os
+    env = {"arena": "XDFM_GRAD_ARENA", "graph": "XDFM_HIP_GRAPH", "deferred": "XDFM_ADAM_DEFERRED"}[feature]
+    if os.environ.get(env, "1") == "0":
+        pytest.skip("%s=0" % env)
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -139,6 +148,7 @@ def test_four_ranks_ragged_batches_and_a_tail_smaller_than_the_world(tmp_path):
 
 @pytest.mark.gpu
 def test_row_parallel_fit_equals_single_process_gpu(tmp_path):
+    _needs_default_env('graph')
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     # 343 rows = 5 full global batches + a ragged one of 23 per epoch (11 + 12 rows: the rank with fewer rows pads its
@@ -153,6 +163,7 @@ def test_row_parallel_four_ranks_with_cold_rows_gpu(tmp_path, monkeypatch):
     """Four ranks on one GPU, vocabularies of thousands of rows (most rows cold, 16-row shards): the deferred table update
     brings a rank's own rows up to date before its gather and replays, inside the step, the rows the other ranks touched;
     replicas must stay bit-identical and follow the single-process run."""
+    _needs_default_env('graph')
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     monkeypatch.setenv("XDFM_TEST_BIG_VOCAB", "1")

@@ -17,6 +17,15 @@ pytestmark = pytest.mark.gpu
 T = torch.from_numpy
 
 
+
+def _needs_default_env(feature):
+    """Tests that assert a feature is ACTIVE skip when the environment switches it off (XDFM_GRAD_ARENA=0 / XDFM_HIP_GRAPH=0 /
+    XDFM_ADAM_DEFERRED=0 are supported ways to run the product; the rest of the suite passes under them)."""
+    import os
+    env = {"arena": "XDFM_GRAD_ARENA", "graph": "XDFM_HIP_GRAPH", "deferred": "XDFM_ADAM_DEFERRED"}[feature]
+    if os.environ.get(env, "1") == "0":
+        pytest.skip("%s=0" % env)
+
 def _dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -1251,6 +1260,7 @@ def test_train_step_keeps_table_gradients_clean_without_table_sized_fills():
     """The model's own train step (eager and graph-replayed) on the kept gradient buffer (ops.GradArena): same
     losses and parameters as with a fresh zero-filled buffer per step (XDFM_GRAD_ARENA=0), never the slow full
     clear, and buffer + marks all zero after every step."""
+    _needs_default_env('graph')
     from deepctr.inputs import DenseFeat, SparseFeat
     from deepctr.models import xDeepFM
     from oracle import xdeepfm_oracle as orc
