@@ -20,6 +20,8 @@ __global__ __launch_bounds__(512) void probe(float* out, long* t, int iters) {
     f32x16 acc[4];
     for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     h8 a, b, b2, fr[8];
+    h8 ar[4][2];
+    for (int k = 0; k < 4; ++k) { ar[k][0] = *(const h8*)(smem + lane * 16 + k * 2048); ar[k][1] = *(const h8*)(smem + lane * 16 + k * 2048 + 1024); }
     f32x16 acc2[4];
     for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc2[k][r] = 0.f;
     for (int r = 0; r < 8; ++r) b2[r] = (_Float16)(r * 0.25f);
@@ -87,6 +89,43 @@ __global__ __launch_bounds__(512) void probe(float* out, long* t, int iters) {
         } else if (MODE == 10) {    // 12 MFMAs alternating between two accumulators
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[k & 7], b, acc[k & 1], 0, 0, 0);
+        } else if (MODE >= 11 && MODE <= 14) {
+            // the forward kernel's step: REG regions of (look-ahead fragments of the next region, MFMAs of this one on
+            // 12 / REG MFMAs); 11: 2 regions x 6 MFMAs (2 row tiles), 12: 1 region x 12 (4 row tiles), 13: as 11 without
+            // the scheduling fences, 14: as 11 with the hi*hi, hi*lo, lo*hi MFMAs of a tile back to back
+            constexpr int REG = MODE == 12 ? 1 : 2;
+            constexpr int TG = 4 / REG;                  // row tiles per region
+            const char* base = st + (it & 7) * 8192;
+            if (it == 0) { b = *(const h8*)(st + 9 * 1024); b2 = *(const h8*)(st + 10 * 1024); }      // random B operands too
+#pragma unroll
+            for (int p = 0; p < REG; ++p) {
+                h8 an[TG][2];
+                const char* nx = p + 1 < REG ? base + (p + 1) * TG * 2048 : st + ((it + 1) & 7) * 8192;
+#pragma unroll
+                for (int k = 0; k < TG; ++k) { an[k][0] = *(const h8*)(nx + k * 2048); an[k][1] = *(const h8*)(nx + k * 2048 + 1024); }
+                if (MODE == 14) {
+#pragma unroll
+                    for (int k = 0; k < TG; ++k) {
+                        acc[TG * p + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[k][0], b, acc[TG * p + k], 0, 0, 0);
+                        acc[TG * p + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[k][0], b2, acc[TG * p + k], 0, 0, 0);
+                        acc[TG * p + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[k][1], b, acc[TG * p + k], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < 3; ++f)
+#pragma unroll
+                        for (int k = 0; k < TG; ++k)
+                            acc[TG * p + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[k][f == 2 ? 1 : 0], f == 1 ? b2 : b, acc[TG * p + k], 0, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < TG; ++k) { ar[k][0] = an[k][0]; ar[k][1] = an[k][1]; }
+                if (MODE != 13) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, TG * 2, 0);
+#pragma unroll
+                    for (int i = 0; i < TG * 3; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         } else if (MODE == 5) {     // 12 MFMAs + barrier
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k & 3], 0, 0, 0);
@@ -97,6 +136,7 @@ __global__ __launch_bounds__(512) void probe(float* out, long* t, int iters) {
     float s = 0.f;
     for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) s += acc[k][r] + acc2[k][r];
     for (int k = 0; k < 8; ++k) s += (float)fr[k][k];
+    for (int k = 0; k < 4; ++k) s += (float)ar[k][0][k] + (float)ar[k][1][k];
     for (int r = 0; r < 8; ++r) s += v[r] + (float)a[r];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if (threadIdx.x == 0) { t[blockIdx.x * 2] = c1 - c0; t[blockIdx.x * 2 + 1] = r1 - r0; }
@@ -129,6 +169,17 @@ static void run(const char* name, int waves, int iters, int per_iter) {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 3) {                 // the forward kernel's region structure against the plain loop
+        const int iters = atoi(argv[1]);
+        for (int rep = 0; rep < 2; ++rep) {
+            run<8>("12 MFMA + 8 ds_read random (plain)", 8, iters, 12);
+            run<11>("2 regions x (4 reads ahead, 6 MFMA)", 8, iters, 12);
+            run<12>("1 region x (8 reads ahead, 12 MFMA)", 8, iters, 12);
+            run<13>("2 regions, no scheduling fences", 8, iters, 12);
+            run<14>("2 regions, a tile's 3 MFMAs back to back", 8, iters, 12);
+        }
+        return 0;
+    }
     if (argc > 2) {                 // dependency chains
         const int iters = atoi(argv[1]);
         for (int waves : {4, 8}) {
