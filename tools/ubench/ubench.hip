@@ -20,7 +20,8 @@ __global__ __launch_bounds__(512) void probe(float* out, long* t, int iters) {
     f32x16 acc[4];
     for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
     h8 a, b, b2, fr[8];
-    h8 ar[4][2];
+    h8 ar[4][2], nb = b, nb2 = b;
+    const float* gin = out;
     for (int k = 0; k < 4; ++k) { ar[k][0] = *(const h8*)(smem + lane * 16 + k * 2048); ar[k][1] = *(const h8*)(smem + lane * 16 + k * 2048 + 1024); }
     f32x16 acc2[4];
     for (int k = 0; k < 4; ++k) for (int r = 0; r < 16; ++r) acc2[k][r] = 0.f;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(512) void probe(float* out, long* t, int iters) {
         } else if (MODE == 10) {    // 12 MFMAs alternating between two accumulators
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fr[k & 7], b, acc[k & 1], 0, 0, 0);
-        } else if (MODE >= 11 && MODE <= 14) {
+        } else if (MODE >= 11 && MODE <= 18) {
             // the forward kernel's step: REG regions of (look-ahead fragments of the next region, MFMAs of this one on
             // 12 / REG MFMAs); 11: 2 regions x 6 MFMAs (2 row tiles), 12: 1 region x 12 (4 row tiles), 13: as 11 without
             // the scheduling fences, 14: as 11 with the hi*hi, hi*lo, lo*hi MFMAs of a tile back to back
@@ -117,6 +118,31 @@ __global__ __launch_bounds__(512) void probe(float* out, long* t, int iters) {
                         for (int k = 0; k < TG; ++k)
                             acc[TG * p + k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[k][f == 2 ? 1 : 0], f == 1 ? b2 : b, acc[TG * p + k], 0, 0, 0);
                 }
+                if (MODE == 15 || MODE == 18) {                  // + the B-operand arithmetic of the CIN step (2 pairs per region)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float x = v[(2 * p + q) & 7], y0 = v[(q + 3) & 7], y1 = v[(q + 5) & 7];
+                        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                        typedef float f2 __attribute__((ext_vector_type(2)));
+                        const f2 z = (f2){x, x} * (f2){y0, y1};
+                        const h2 hi = __builtin_convertvector(z, h2);
+                        const unsigned hb = __builtin_bit_cast(unsigned, hi);
+                        float r0, r1;
+                        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x), "v"(y0), "v"(hb));
+                        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x), "v"(y1), "v"(hb));
+                        const f2 rr = {r0, r1};
+                        const h2 lo = __builtin_convertvector(rr, h2);
+                        nb[2 * (2 * p + q)] = hi.x; nb[2 * (2 * p + q) + 1] = hi.y;
+                        nb2[2 * (2 * p + q)] = lo.x; nb2[2 * (2 * p + q) + 1] = lo.y;
+                    }
+                }
+                if ((MODE == 16 || MODE == 18) && p == REG - 1 && (it & 1)) __builtin_amdgcn_s_barrier();
+                if ((MODE == 17 || MODE == 18) && p == REG - 1 && (it & 1)) {
+                    const unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + 40000 + (threadIdx.x >> 6) * 2048));
+                    const float* gsrc = gin + ((it >> 1) & 15) * 4096 + (threadIdx.x >> 6) * 512 + lane * 4;
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024" ::"v"(gsrc), "s"(lo_) : "memory", "m0");
+                    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                }
 #pragma unroll
                 for (int k = 0; k < TG; ++k) { ar[k][0] = an[k][0]; ar[k][1] = an[k][1]; }
                 if (MODE != 13) {
@@ -126,6 +152,7 @@ __global__ __launch_bounds__(512) void probe(float* out, long* t, int iters) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            if (MODE == 15 || MODE == 18) { b = nb; b2 = nb2; }
         } else if (MODE == 5) {     // 12 MFMAs + barrier
 #pragma unroll
             for (int k = 0; k < 12; ++k) acc[k & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[k & 3], 0, 0, 0);
@@ -177,6 +204,10 @@ int main(int argc, char** argv) {
             run<12>("1 region x (8 reads ahead, 12 MFMA)", 8, iters, 12);
             run<13>("2 regions, no scheduling fences", 8, iters, 12);
             run<14>("2 regions, a tile's 3 MFMAs back to back", 8, iters, 12);
+            run<15>("2 regions + B-operand arithmetic", 8, iters, 12);
+            run<16>("2 regions + barrier every 2 steps", 8, iters, 12);
+            run<17>("2 regions + LDS-DMA 2 KB per wave per 2 steps", 8, iters, 12);
+            run<18>("2 regions + all three", 8, iters, 12);
         }
         return 0;
     }
