@@ -58,7 +58,9 @@ def test_workspace_size_queries():
         assert lib.xdfm_cin_bwd_w_ws_elems(6, 5, 3, 40) == 3 * 32 * 32 * 2
         _lib.set_option("cin_math", 1)            # f16x3 kernels: 128-float header + 2 KB (hi + lo) per (step, row tile)
         assert lib.xdfm_cin_fwd_pack_elems(128, 128, 26) == 128 + 1 * (16 * 13 + 2) * 4 * 512    # 104 stages of 2 steps + a spare stage
-        assert lib.xdfm_cin_fwd_pack_elems(256, 26, 26) == 128 + 1 * (3 * 13 + 4 + 1) * 8 * 512   # ragged last block: 4 steps; whole ring stages (1 step at 8 row tiles) + a spare one
+        # ragged last block: 4 steps; whole ring stages (1 step at 8 row tiles) + a spare one.  Hp == m: the level can be
+        # level 0 (x_prev is x0), whose folded pack (182 pairs i <= j per lane half = 23 steps, + a spare stage) follows
+        assert lib.xdfm_cin_fwd_pack_elems(256, 26, 26) == 128 + 1 * (3 * 13 + 4 + 1) * 8 * 512 + 128 + (23 + 1) * 8 * 512
         assert lib.xdfm_cin_fwd_pack_elems(512, 26, 22) == 128 + 2 * (3 * 11 + 3 + 1) * 8 * 512
         assert lib.xdfm_cin_fwd_pack_elems(128, 128, 7) == 1 * (128 * 4 + 4) * 64 * 4             # odd m: fp32 kernel
         assert lib.xdfm_cin_bwd_pack_elems(128, 128, 26) == 128 + (4 * 26 * 8 + 2 * 8) * 512

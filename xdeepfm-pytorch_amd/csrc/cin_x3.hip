@@ -39,6 +39,17 @@ X3Geom x3_fwd_geom(int H, int Hp, int m) {
     return g;
 }
 
+// level 0 over the folded pair list: one block of x3_sym_steps(m) steps, no x_prev rows
+X3Geom x3_fwd_geom_sym(int H, int m) {
+    X3Geom g = x3_fwd_geom(H, m, m);
+    g.MP = x3_sym_steps(m);
+    g.FB = 1; g.RH = 0; g.TS = 0;
+    g.NS = g.MP;
+    g.SPS = x3_fwd_sps_sym(g.MT, x3_terms() == 1 ? 1 : 3);
+    g.NSA = (ceil_div(g.NS, g.SPS) + 1) * g.SPS;
+    return g;
+}
+
 bool x3_fwd_usable(int H, int Hp, int m) {
     (void)Hp;
     const int nt = x3_terms();
@@ -134,6 +145,56 @@ __device__ __forceinline__ void x3_fwd_pack_one(const float* __restrict__ W, int
     }
 }
 
+// folded pack of level 0 (x3_sym_*), same fragment layout with the SYM geometry; its own header: the folded weights
+// reach twice the maximum, so their scale is half the one of the plain pack ([0] = sW/2, [1] = 2/sW).  `hdr` = the plain
+// pack's header (partial maxima of |W|).
+__device__ __forceinline__ void x3_fwd_pack_sym_one(const float* __restrict__ W, int H, int m, const X3Geom& G, int nparts,
+                                                    const float* __restrict__ hdr, float* __restrict__ pack, long idx, int nt) {
+    const float sW = nt == 3 ? 0.5f * x3_weight_scale(hdr, nparts) : 1.f;
+    if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
+    const int lane = (int)(idx & 63);
+    long rest = idx >> 6;
+    const int mt = (int)(rest % G.MT); rest /= G.MT;
+    const int g = (int)(rest % G.NSA);
+    const int mb = (int)(rest / G.NSA);
+    const int r = lane & 31, hh = lane >> 5;
+    const int row = (mb * G.MT + mt) * 32 + r;
+    const float* __restrict__ Wr = W + (long)(row < H ? row : 0) * ((long)m * m);
+    h8 hi, lo;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int q = 8 * g + t;
+        float v = 0.f;
+        if (g < G.NS && row < H && q < x3_sym_pairs(m)) {
+            const int i = x3_sym_i(m, q), j = x3_sym_j(m, q);
+            const int a = hh ? m - 1 - i : i, b = hh ? m - 1 - j : j;
+            if (a == b) v = Wr[a * m + a];
+            else if (!(hh && i + j == m - 1)) v = Wr[a * m + b] + Wr[b * m + a];
+            v *= sW;
+        }
+        if (nt == 3) {
+            const _Float16 x = (_Float16)v;
+            hi[t] = x;
+            lo[t] = (_Float16)(v - (float)x);
+        } else {
+            hi[t] = __builtin_bit_cast(_Float16, (__bf16)v);
+        }
+    }
+    if (nt == 3) {
+        h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + (((long)mb * G.NSA + g) * G.MT + mt) * 128 + lane;
+        dst[0] = hi;
+        dst[64] = lo;
+    } else {
+        reinterpret_cast<h8*>(pack + X3_HDR)[(((long)mb * G.NSA + g) * G.MT + mt) * 64 + lane] = hi;
+    }
+}
+
+__global__ void x3_fwd_pack_sym_kernel(const float* __restrict__ W, int H, int m, X3Geom G, int nparts,
+                                       const float* __restrict__ hdr, float* __restrict__ pack, int nt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < (long)G.MB * G.NSA * G.MT * 64) x3_fwd_pack_sym_one(W, H, m, G, nparts, hdr, pack, idx, nt);
+}
+
 __global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3Geom G, int nparts,
                                    float* __restrict__ pack, int nt) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,10 +202,19 @@ __global__ void x3_fwd_pack_kernel(const float* __restrict__ W, int H, int Hp, i
 }
 
 // ---------------------------------------------------------------------------------------------
-size_t x3_fwd_pack_elems(int H, int Hp, int m) {
+static size_t x3_fwd_pack_plain_elems(int H, int Hp, int m) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
     // 2 KB (hi + lo) = 512 floats per (step, row tile); bf16: 1 KB
     return (size_t)X3_HDR + (size_t)g.MB * g.NSA * g.MT * (x3_terms() == 3 ? 512 : 256);
+}
+// a level whose x_prev can be x0 (Hp == m) carries the folded pack behind the plain one (whether the level IS level 0
+// is only known when it is launched: x_prev == x0)
+static bool x3_fwd_has_sym(int Hp, int m) { return Hp == m && x3_sym_m(m); }
+static size_t x3_fwd_sym_offset(int H, int Hp, int m) { return (size_t)round_up((long)x3_fwd_pack_plain_elems(H, Hp, m), 4); }
+size_t x3_fwd_pack_elems(int H, int Hp, int m) {
+    if (!x3_fwd_has_sym(Hp, m)) return x3_fwd_pack_plain_elems(H, Hp, m);
+    const X3Geom g = x3_fwd_geom_sym(H, m);
+    return x3_fwd_sym_offset(H, Hp, m) + (size_t)X3_HDR + (size_t)g.MB * g.NSA * g.MT * (x3_terms() == 3 ? 512 : 256);
 }
 
 int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
@@ -155,6 +225,12 @@ int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
     const long threads = (long)g.MB * g.NSA * g.MT * 64;
     hipLaunchKernelGGL(x3_fwd_pack_kernel, dim3(ceil_div(threads, 256)), dim3(256), 0, st, W, H, Hp, m, g,
                        x3_absmax_blocks(total), pack, nt);
+    if (x3_fwd_has_sym(Hp, m)) {
+        const X3Geom gs = x3_fwd_geom_sym(H, m);
+        const long ts = (long)gs.MB * gs.NSA * gs.MT * 64;
+        hipLaunchKernelGGL(x3_fwd_pack_sym_kernel, dim3(ceil_div(ts, 256)), dim3(256), 0, st, W, H, m, gs,
+                           x3_absmax_blocks(total), pack, pack + x3_fwd_sym_offset(H, Hp, m), nt);
+    }
     return xdfm_check_launch("cin_fwd_pack (f16x3 / bf16)");
 }
 
@@ -165,6 +241,8 @@ int x3_level_fwd(const float* xp, const float* x0, const float* pack, const floa
     act |= ((xdfm_opt(OPT_DBG) >> 6) & 255) << 8;     // timing experiments (results become wrong): see the kernels' `dbg`
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd: packed weights must be 16-byte aligned");
     if (nt != 3 && g.MT < 4) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd (bf16): no kernel for MT=%d", g.MT);
+    if (xp == x0 && x3_fwd_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0)
+        return x3_level_fwd_sym(x0, pack + x3_fwd_sym_offset(H, Hp, m), bias, H, m, N, x3_fwd_geom_sym(H, m), nt, act, out, st);
     if (m == 26) return X3_FWD_DISPATCH_M(26);
     if (m == 22) return X3_FWD_DISPATCH_M(22);
     if (m < 22) return x3_level_fwd_ma(xp, x0, pack, bias, H, Hp, m, N, g, nt, act, out, st);
@@ -246,10 +324,11 @@ struct X3PackJobs {
     const float* W[X3_MAXJOBS];
     float* fwd[X3_MAXJOBS];
     float* bwd[X3_MAXJOBS];
+    float* fsym[X3_MAXJOBS];                 // folded forward pack of a level with Hp == m (null otherwise)
     int H[X3_MAXJOBS], Hp[X3_MAXJOBS], m[X3_MAXJOBS], nparts[X3_MAXJOBS];
-    long nW[X3_MAXJOBS], fthreads[X3_MAXJOBS], bthreads[X3_MAXJOBS];
+    long nW[X3_MAXJOBS], fthreads[X3_MAXJOBS], bthreads[X3_MAXJOBS], sthreads[X3_MAXJOBS];
     int nt;
-    X3Geom fg[X3_MAXJOBS];
+    X3Geom fg[X3_MAXJOBS], sg[X3_MAXJOBS];
     X3BwxGeom bg[X3_MAXJOBS];
 };
 
@@ -283,9 +362,13 @@ __global__ __launch_bounds__(1024) void x3_absmax_multi_kernel(const X3PackJobs 
 }
 
 __global__ __launch_bounds__(256) void x3_pack_multi_kernel(const X3PackJobs J) {
-    const int l = blockIdx.y >> 1, dir = blockIdx.y & 1;
+    const int l = blockIdx.y / 3, dir = blockIdx.y - 3 * l;
     const long stride = (long)gridDim.x * blockDim.x;
-    if (dir == 0) {
+    if (dir == 2) {
+        if (!J.fsym[l]) return;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.sthreads[l]; idx += stride)
+            x3_fwd_pack_sym_one(J.W[l], J.H[l], J.m[l], J.sg[l], J.nparts[l], J.fwd[l], J.fsym[l], idx, J.nt);
+    } else if (dir == 0) {
         if (!J.fwd[l]) return;
         for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.fthreads[l]; idx += stride)
             x3_fwd_pack_one(J.W[l], J.H[l], J.Hp[l], J.m[l], J.fg[l], J.nparts[l], J.fwd[l], idx, J.nt);
@@ -605,6 +688,10 @@ int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st) {
         J.fg[l] = x3_fwd_geom(j.H, j.Hp, j.m);
         J.bg[l] = x3_bwx_geom(j.H, j.Hp, j.m);
         J.fthreads[l] = (long)J.fg[l].MB * J.fg[l].NSA * J.fg[l].MT * 64;
+        const bool sym = l < L && j.fwd_pack && x3_fwd_has_sym(j.Hp, j.m);
+        J.sg[l] = x3_fwd_geom_sym(j.H, j.m);
+        J.fsym[l] = sym ? j.fwd_pack + x3_fwd_sym_offset(j.H, j.Hp, j.m) : nullptr;
+        J.sthreads[l] = (long)J.sg[l].MB * J.sg[l].NSA * J.sg[l].MT * 64;
         J.bthreads[l] = ((long)J.bg[l].NT * J.bg[l].HBT + 2 * J.bg[l].HBS) * 64;
         if (l < L) {
             if (J.fthreads[l] > maxthreads) maxthreads = J.fthreads[l];
@@ -616,6 +703,6 @@ int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st) {
     if (J.nt == 3) hipLaunchKernelGGL(x3_absmax_multi_kernel, dim3(maxparts, L), dim3(1024), 0, st, J);
     int gx = ceil_div(maxthreads, 256);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(x3_pack_multi_kernel, dim3(gx, 2 * L), dim3(256), 0, st, J);
+    hipLaunchKernelGGL(x3_pack_multi_kernel, dim3(gx, 3 * L), dim3(256), 0, st, J);
     return xdfm_check_launch("cin_pack_all");
 }

@@ -83,7 +83,23 @@ __device__ __forceinline__ float x3_col_absmax(const float* __restrict__ col, lo
 // NT = MFMA terms per product: 3 (f16x3: hi / lo fp16 halves, range-fitted) or 1 (bf16 operands, no scales)
 // EXP: timing experiments compiled for one instance only (results wrong): 1 no B-operand build, 2 no barriers,
 // 4 no weight DMA inside the loop (tools/fwd_phases.py)
-template <int MT, int M, int NW, int R = X3_RING, int NT = 3, int EXP = 0>
+// SYM: level 0 (x_prev is x0) over the folded pair list of xdfm_internal.h's x3_sym_*: no x_prev rows, one block of
+// x3_sym_steps(M) steps, both factors of a product from the x0 registers
+template <int M>
+struct X3SymTab {
+    signed char i[8 * x3_sym_steps(M) + 2], j[8 * x3_sym_steps(M) + 2];
+    constexpr X3SymTab() : i(), j() {
+        for (int q = 0; q < 8 * x3_sym_steps(M) + 2; ++q) {
+            const bool pad = q >= x3_sym_pairs(M);          // padding slots: any field (their weights are 0)
+            i[q] = (signed char)(pad ? 0 : x3_sym_i(M, q));
+            j[q] = (signed char)(pad ? 0 : x3_sym_j(M, q));
+        }
+    }
+};
+template <int M>
+__device__ constexpr X3SymTab<M> x3_symtab{};
+
+template <int MT, int M, int NW, int R = X3_RING, int NT = 3, int EXP = 0, bool SYM = false>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ pack,
     const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out) {
@@ -92,11 +108,12 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     constexpr int FRT = NT == 3 ? 2 : 1;        // 1-KB fragments per row tile (hi, lo | bf16)
     constexpr int FR = FRT * MT;                // 1-KB fragments per step
     constexpr int STEPB = FR * 1024;            // bytes of packed weights per step
-    constexpr int SPS = x3_fwd_sps(MT, NT, M);  // steps per ring stage: one barrier and one DMA batch per stage
+    constexpr int NSTEP = SYM ? x3_sym_steps(M) : MP;   // steps of a block (SYM: the whole contraction is one block)
+    constexpr int SPS = SYM ? x3_fwd_sps_sym(MT, NT) : x3_fwd_sps(MT, NT, M);  // steps per ring stage: one barrier and one DMA batch per stage
     constexpr int STAGE = SPS * STEPB;          // bytes
     constexpr int FPW = SPS * FR / NW;          // LDS-DMA instructions per wave and stage
     static_assert((SPS * FR) % NW == 0, "every wave issues the same number of LDS-DMA pieces");
-    static_assert(MP >= SPS * (R - 1) + 1, "the next block's x_prev rows must be published before the block's last step");
+    static_assert(SYM || MP >= SPS * (R - 1) + 1, "the next block's x_prev rows must be published before the block's last step");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, hh = lane >> 5;
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             x3_lds_dma4(xp + (long)i * N + col, xbuf_lo + (buf * 8 * XCOLS + e) * 4);
         }
     };
-    dma_xp(0, 0);
+    if constexpr (!SYM) dma_xp(0, 0);
     // the ring runs R - 1 stages ahead of the stage being read (R slots); the packed stream ends with a spare stage
     const char* wlast = wsrc + (long)(G.NSA - SPS) * STEPB;   // last stage that exists (reads past it are clamped to it)
 #pragma unroll
@@ -166,7 +183,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     }
     float ap = 0.f;
     if (NT != 3) {
-    } else if (xp == x0) {
+    } else if (SYM || xp == x0) {
         ap = a0;
     } else {
         ap = x3_col_absmax(xp + nc, N, hh, Hp);
@@ -176,6 +193,14 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const float s0 = NT == 3 ? x3_pow2_scale(a0, 7) : 1.f, sp = NT == 3 ? x3_pow2_scale(ap, 7) : 1.f;
 #pragma unroll
     for (int j = 0; j < M; ++j) x0r[j] *= s0;
+    if constexpr (SYM) {                        // lane half 1: the fields in reverse order
+#pragma unroll
+        for (int j = 0; j < M / 2; ++j) {
+            const float u = x0r[j], v = x0r[M - 1 - j];
+            x0r[j] = hh ? v : u;
+            x0r[M - 1 - j] = hh ? u : v;
+        }
+    }
 
     f32x16 acc[MT];
 #pragma unroll
@@ -209,6 +234,20 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
             bl[2 * t2] = lo.x; bl[2 * t2 + 1] = lo.y;
         }
     };
+    // SYM: slots q = 8s + 2*t2, + 1 of the pair list, both factors from the (per lane half ordered) x0 registers
+    auto build_b_sym = [&](int s, h8& bh, h8& bl, int T0, int T1) {
+#pragma unroll
+        for (int t2 = 0; t2 < 4; ++t2) {
+            if (t2 < T0 || t2 >= T1) continue;
+            const int q = 8 * s + 2 * t2;
+            const int i0 = x3_symtab<M>.i[q], j0 = x3_symtab<M>.j[q], i1 = x3_symtab<M>.i[q + 1], j1 = x3_symtab<M>.j[q + 1];
+            h2 hi = h2{0, 0}, lo = h2{0, 0};
+            if constexpr (NT == 3) x3_split_prod2(x0r[i0], x0r[j0], x0r[i1], x0r[j1], hi, lo);
+            else hi = x3_bf16_pair(x0r[i0] * x0r[j0], x0r[i1] * x0r[j1]);
+            bh[2 * t2] = hi.x; bh[2 * t2 + 1] = hi.y;
+            bl[2 * t2] = lo.x; bl[2 * t2 + 1] = lo.y;
+        }
+    };
     // A fragments of row-tile pair `pair` of the stage in ring slot `slot_off`
     constexpr int TG = NT == 3 ? 2 : 4;         // row tiles per region (6 / 4 MFMAs: ~200 / 130 cycles of matrix pipe)
     constexpr int P = MT / TG;                  // regions per step
@@ -226,9 +265,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     // block 0's x_prev rows (issued before the ring's first stages) and stage 0 have landed, for every wave
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * FPW) : "memory");
     __builtin_amdgcn_s_barrier();
-    read_xp(0, G.FB > 0 ? 4 : G.RH, xv);
     h8 bh, bl;
-    build_b(0, xv, bh, bl, 0, 4);
+    if constexpr (SYM) {
+        build_b_sym(0, bh, bl, 0, 4);
+    } else {
+        read_xp(0, G.FB > 0 ? 4 : G.RH, xv);
+        build_b(0, xv, bh, bl, 0, 4);
+    }
     h8 a[TG][FRT];                              // the row tiles about to be multiplied (loaded one region ahead)
     load_pair(0, 0, a);
     // ring state (wave-uniform): LDS offsets of the step being multiplied and of the one after it (steps sit back to
@@ -245,13 +288,13 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     // barrier; stage k - 1 may still have reads in flight) takes the DMA of stage k + R - 2.
     auto block_steps = [&](int blk, int nsteps_dyn, auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
-        const bool has_next = blk + 1 < nblk;
+        const bool has_next = !SYM && blk + 1 < nblk;
         xp_todo = has_next;
 #pragma unroll
-        for (int s = 0; s < MP; ++s) {
+        for (int s = 0; s < NSTEP; ++s) {
             if (FULL || s < nsteps_dyn) {       // wave-uniform
             h8 nh = bh, nl = bl;                // operand of the step after this one
-            const bool more = s + 1 < MP && (FULL || s + 1 < nsteps_dyn);
+            const bool more = s + 1 < NSTEP && (FULL || s + 1 < nsteps_dyn);
             const bool wrap = !more && has_next;
             if (wrap) read_xp(blk + 1, blk + 1 < G.FB ? 4 : G.RH, xn);   // landed and published R - 2 stage boundaries after the first one of this block
 #pragma unroll
@@ -291,6 +334,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
                     mfmas(0, NM);
                 }
                 if constexpr (EXP & 1) {
+                } else if (SYM) {
+                    if (more) build_b_sym(s + 1, nh, nl, p * TPR, p * TPR + TPR);
                 } else if (more) build_b(s + 1, xv, nh, nl, p * TPR, p * TPR + TPR);
                 else if (wrap) build_b(0, xn, nh, nl, p * TPR, p * TPR + TPR);
 #pragma unroll
@@ -318,8 +363,12 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
         }
     };
     const long tc1 = __builtin_readcyclecounter(), tr1 = __builtin_amdgcn_s_memrealtime();
-    for (int blk = 0; blk < ((dbg & 2) ? 1 : G.FB); ++blk) block_steps(blk, MP, std::true_type{});
-    if (G.TS > 0) block_steps(G.FB, G.TS, std::false_type{});
+    if constexpr (SYM) {
+        block_steps(0, NSTEP, std::true_type{});
+    } else {
+        for (int blk = 0; blk < ((dbg & 2) ? 1 : G.FB); ++blk) block_steps(blk, MP, std::true_type{});
+        if (G.TS > 0) block_steps(G.FB, G.TS, std::false_type{});
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the look-ahead stages must land before LDS is released
     const long tc2 = __builtin_readcyclecounter(), tr2 = __builtin_amdgcn_s_memrealtime();
 
@@ -350,30 +399,30 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
 
 // NW waves (= 32*NW columns) share one weight ring: 8 waves halve the L2 -> LDS traffic of the ring (every
 // workgroup streams the whole packed matrix: 512 x 1.7 MB per launch at config 2 with 4 waves)
-template <int MT, int M, int NT>
+template <int MT, int M, int NT, bool SYM = false>
 static int launch_x3(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, long N,
                      const X3Geom& g, int act, float* out, hipStream_t st) {
     constexpr int FR = (NT == 3 ? 2 : 1) * MT;
     constexpr int NWMAX = FR % 8 == 0 ? 8 : 4;
     static_assert(FR % 4 == 0, "a ring stage is dealt to 4 or 8 waves");
     // ring (X3_RING stages of SPS steps) + bias of the workgroup's rows + two x_prev buffers
-    constexpr size_t RING = (size_t)X3_RING * x3_fwd_sps(MT, NT, M) * FR * 1024;
+    constexpr size_t RING = (size_t)X3_RING * (SYM ? x3_fwd_sps_sym(MT, NT) : x3_fwd_sps(MT, NT, M)) * FR * 1024;
     if constexpr (NWMAX == 8) {
         if (xdfm_opt(OPT_X3_WAVES) != 4 && N >= 256 * 64) {
             const dim3 grid(ceil_div(N, 32 * NWMAX), g.MB), block(64 * NWMAX);
             const size_t ldsx = RING + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
-            if constexpr (MT == 4 && M == 26 && NT == 3) {
+            if constexpr (MT == 4 && M == 26 && NT == 3 && !SYM) {
                 const int e = (act >> 8) >> 3;          // dbg bits 8 / 16 / 32 -> EXP 1 / 2 / 4 (7 = all three)
 #define X3_EXP_CASE(E) if (e == E) { hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT, E>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out); return xdfm_check_launch("cin_level_fwd (experiment)"); }
                 X3_EXP_CASE(1) X3_EXP_CASE(2) X3_EXP_CASE(3) X3_EXP_CASE(4) X3_EXP_CASE(5) X3_EXP_CASE(6) X3_EXP_CASE(7)
 #undef X3_EXP_CASE
             }
-            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
+            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT, 0, SYM>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
             return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
         }
     }
     const size_t lds4 = RING + 32 * MT * sizeof(float) + (size_t)2 * 8 * 128 * sizeof(float);
-    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4, X3_RING, NT>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds4, st, xp, x0, pack,
+    hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4, X3_RING, NT, 0, SYM>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds4, st, xp, x0, pack,
                        bias, H, Hp, N, g, act, out);
     return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
 }
@@ -386,3 +435,11 @@ static int launch_x3(const float* xp, const float* x0, const float* pack, const 
                             : launch_x3<8, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, st))                       \
              : (g.MT == 4 ? launch_x3<4, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                          \
                           : launch_x3<8, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)))
+
+// level 0 with folded weights (x_prev is x0): same choice of instance, SYM kernels
+#define X3_FWD_DISPATCH_SYM(MV)                                                                                        \
+    (nt == 3 ? (g.MT == 2   ? launch_x3<2, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                  \
+                : g.MT == 4 ? launch_x3<4, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                  \
+                            : launch_x3<8, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st))                 \
+             : (g.MT == 4 ? launch_x3<4, MV, 1, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                    \
+                          : launch_x3<8, MV, 1, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)))

@@ -29,6 +29,7 @@ enum {
     OPT_LAST_FWD,        // read-only probes: arithmetic of the kernel the last xdfm_cin_level_fwd / _bwd_x / _bwd_w call
     OPT_LAST_BWX,        //   launched: 0 = v_mfma_f32_32x32x2_f32, 1 = f16x3, 2 = bf16 (tests assert which kernel ran)
     OPT_LAST_BWW,
+    OPT_X3_SYM,          // 1 (default) = level 0 (x_prev is x0) contracts over the pairs i <= j with folded weights; 0 = full (i, j) grid
     OPT_COUNT
 };
 
@@ -91,6 +92,28 @@ constexpr __host__ __device__ inline int x3_fwd_sps(int MT, int nt, int m) {
     while (sps > 1 && sps > lim) sps >>= 1;
     return sps;
 }
+// Level 0 of the CIN multiplies x0 with itself: Z[(i, j)] == Z[(j, i)], so the contraction runs over the pairs
+// i <= j with the folded weights W[h][(i, j)] + W[h][(j, i)] (W[h][(i, i)] on the diagonal).  The forward kernel's two
+// lane halves hold the same column, the second one with its x0 registers in reverse field order: slot q of the pair
+// list {(i, j): i <= j, i + j <= m - 1} (rows i = 0 .. m/2 - 1 of lengths m - 2i) then means (i, j) to lane half 0 and
+// (m-1-i, m-1-j) to lane half 1 -- together every pair; those with i + j == m - 1 twice, so half 1's weight is 0 there.
+constexpr __host__ __device__ inline int x3_sym_pairs(int m) { return (m / 2) * (m / 2 + 1); }     // slots per lane half (even)
+constexpr __host__ __device__ inline int x3_sym_steps(int m) { return (x3_sym_pairs(m) + 7) / 8; }
+constexpr __host__ __device__ inline int x3_sym_i(int m, int q) {       // m / 2 for the padding slots behind the list
+    int i = 0;
+    while (i < m / 2 && q >= m - 2 * i) { q -= m - 2 * i; ++i; }
+    return i;
+}
+constexpr __host__ __device__ inline int x3_sym_j(int m, int q) {
+    int i = 0;
+    while (i < m / 2 && q >= m - 2 * i) { q -= m - 2 * i; ++i; }
+    return i + q;
+}
+constexpr __host__ __device__ inline int x3_fwd_sps_sym(int MT, int nt) {
+    const int sps = X3_STAGE_KB / ((nt == 3 ? 2 : 1) * MT);
+    return sps < 1 ? 1 : sps;
+}
+static inline bool x3_sym_m(int m) { return m == 22 || m == 26; }      // field counts with a folded-level-0 kernel instance
 struct X3Geom {
     int MT, MB;           // row tiles (of 32) per wave, row groups (blockIdx.y)
     int MP;               // MFMA steps per full block of 8 x_prev rows (= m / 2)
@@ -98,11 +121,15 @@ struct X3Geom {
     int SPS, NSA;         // steps per ring stage; steps stored per row group (whole stages + one spare, zero past NS)
 };
 X3Geom x3_fwd_geom(int H, int Hp, int m);
+X3Geom x3_fwd_geom_sym(int H, int m);          // level 0 with folded weights (x3_sym_*): one block of x3_sym_steps(m) steps
 bool x3_fwd_usable(int H, int Hp, int m);
 size_t x3_fwd_pack_elems(int H, int Hp, int m);
 int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
 int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
                  int act, float* out, hipStream_t st);
+// level 0 with folded weights (cin_x3_fwd_sym.hip; m with x3_sym_m): `pack` = the folded pack, g = x3_fwd_geom_sym
+int x3_level_fwd_sym(const float* x0, const float* pack, const float* bias, int H, int m, long N, const X3Geom& g, int nt,
+                     int act, float* out, hipStream_t st);
 // instances for the other even field counts (cin_x3_fwd_ma.hip: m < 22, cin_x3_fwd_mb.hip: 22 < m <= 40)
 int x3_level_fwd_ma(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
                     const X3Geom& g, int nt, int act, float* out, hipStream_t st);
