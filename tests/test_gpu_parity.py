@@ -419,7 +419,11 @@ def test_cin_f16x3_range_fitting_corners(case):
         H = w.shape[0]
         g, ww = c.weight.grad.double().reshape(H, -1, m), w.grad.reshape(H, -1, m)
         dw = max(dw, ((g - ww).abs().amax(dim=1) / ww.abs().amax(dim=1).clamp_min(1e-300)).max().item())
-    assert per_ex < 1e-5 and dx < 1e-5 and dw < 1e-5, (case, per_map, per_ex, dx, dw)
+    # level 0 runs on folded weights W(i,j) + W(j,i), range-fitted with half the level's scale (the sums reach twice the
+    # maximum): weights 2^20 below the maximum carry an absolute error of 2^-39 instead of 2^-40 of it -- visible only in
+    # this corner (measured 1.7e-5; 8e-6 with the full (i, j) grid, option x3_sym = 0)
+    dx_bound = 2.5e-5 if case == "weight_row" else 1e-5
+    assert per_ex < 1e-5 and dx < dx_bound and dw < 1e-5, (case, per_map, per_ex, dx, dw)
     assert per_map < (1e-5 if case != "weight_row" else 4e-5), (case, per_map)
 
 

@@ -58,4 +58,38 @@ for sym in (0, 1):
     rms = d.pow(2).mean().sqrt().item() / ref_out.pow(2).mean().sqrt().item()
     print("x3_sym=%d forward H=%d m=%d N=%d: %.1f us, max err / max |out| = %.2e, rms err / rms out = %.2e" % (
         sym, H, m, N, t, err, rms), flush=True)
+
+# dX: gradient of sum(dOut * (W Z)) wrt x0, both factors
+xs_g = x0[:, cols].double().requires_grad_(True)
+Zg = (xs_g[:, None, :] * xs_g[None, :, :]).reshape(m * m, -1)
+((W.double() @ Zg) * dOut[:, cols].double()).sum().backward()
+ref_g = xs_g.grad
+Hc = min(H, 256)                                   # rows of the contraction per dX launch
+Wc = W[:Hc].contiguous()
+Zg = (xs_g[:, None, :] * xs_g[None, :, :]).reshape(m * m, -1)
+xs_g.grad = None
+((Wc.double() @ Zg) * dOut[:Hc, cols].double()).sum().backward()
+ref_g = xs_g.grad
+for sym in (0, 1):
+    _lib.set_option("x3_sym", sym)
+    wz = torch.empty(lib.xdfm_cin_bwd_pack_elems(Hc, m, m), dtype=torch.float32, device=dev)
+    _lib.check(lib.xdfm_cin_bwd_pack(Wc.data_ptr(), Hc, m, m, wz.data_ptr(), st), "bwd pack")
+    dxp = torch.full((m, N), 7.0, device=dev)
+    dx0 = torch.full((m, N), 7.0, device=dev)
+    dOc = dOut[:Hc].contiguous()
+
+    def bwx():
+        _lib.check(lib.xdfm_cin_level_bwd_x_ex(dOc.data_ptr(), x0.data_ptr(), x0.data_ptr(), wz.data_ptr(), Hc, m, m, N,
+                                               dxp.data_ptr(), dx0.data_ptr(), 3, st), "bwd_x")
+    t = timed(bwx)
+    d = (dxp + dx0)[:, cols].double() - ref_g
+    err = d.abs().max().item() / ref_g.abs().max().item()
+    rms = d.pow(2).mean().sqrt().item() / ref_g.pow(2).mean().sqrt().item()
+    # accumulate mode: a second call with flags 0 doubles the total
+    _lib.check(lib.xdfm_cin_level_bwd_x_ex(dOc.data_ptr(), x0.data_ptr(), x0.data_ptr(), wz.data_ptr(), Hc, m, m, N,
+                                           dxp.data_ptr(), dx0.data_ptr(), 0, st), "bwd_x")
+    d2 = (dxp + dx0)[:, cols].double() - 2 * ref_g
+    err2 = d2.abs().max().item() / ref_g.abs().max().item()
+    print("x3_sym=%d dX H=%d m=%d N=%d: %.1f us, max err / max |g| = %.2e, rms err / rms g = %.2e; accumulated twice: %.2e" % (
+        sym, Hc, m, N, t, err, rms, err2), flush=True)
 _lib.set_option("x3_sym", 1)

@@ -312,6 +312,56 @@ __device__ __forceinline__ void x3_bwx_pack_one(const float* __restrict__ W, int
     }
 }
 
+// folded pack of level 0 for the dX kernel of cin_x3_bwx_sym.hip: [tile t < m/2][hb < HBT][p][lane][8 halves]; row r of
+// tile t is the pair (i = r, j = t) for r <= t, (i = 31-r, j = m-1-t) for r >= 32-m+t, nothing in between; element
+// W'[h = 16*hb + 8*hh + e][(i, j)] * sW / 2 with W'(i, j) = W(i, j) + W(j, i), W(i, i) on the diagonal.  Own header as in
+// the forward's folded pack; `hdr` = the plain pack's header (partial maxima of |W|).
+__device__ __forceinline__ void x3_bwx_pack_sym_one(const float* __restrict__ W, int H, int m, const X3BwxGeom& G, int nparts,
+                                                    const float* __restrict__ hdr, float* __restrict__ pack, long idx, int nt) {
+    const float sW = nt == 3 ? 0.5f * x3_weight_scale(hdr, nparts) : 1.f;
+    if (idx == 0) { pack[0] = sW; pack[1] = 1.f / sW; }
+    const int lane = (int)(idx & 63);
+    long rest = idx >> 6;
+    const int hb = (int)(rest % G.HBT);
+    const int t = (int)(rest / G.HBT);
+    const int r = lane & 31, hh = lane >> 5;
+    int i = -1, j = 0;
+    if (t < m / 2) {
+        if (r <= t) { i = r; j = t; }
+        else if (31 - r <= m - 1 - t) { i = 31 - r; j = m - 1 - t; }
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int h = 16 * hb + 8 * hh + e;
+        float v = 0.f;
+        if (i >= 0 && h < H) {
+            const float* __restrict__ Wr = W + (long)h * ((long)m * m);
+            v = (i == j ? Wr[i * m + i] : Wr[i * m + j] + Wr[j * m + i]) * sW;
+        }
+        if (nt == 3) {
+            const _Float16 x = (_Float16)v;
+            hi[e] = x;
+            lo[e] = (_Float16)(v - (float)x);
+        } else {
+            hi[e] = __builtin_bit_cast(_Float16, (__bf16)v);
+        }
+    }
+    if (nt == 3) {
+        h8* dst = reinterpret_cast<h8*>(pack + X3_HDR) + ((long)t * G.HBT + hb) * 128 + lane;
+        dst[0] = hi;
+        dst[64] = lo;
+    } else {
+        reinterpret_cast<h8*>(pack + X3_HDR)[((long)t * G.HBT + hb) * 64 + lane] = hi;
+    }
+}
+
+__global__ void x3_bwx_pack_sym_kernel(const float* __restrict__ W, int H, int m, X3BwxGeom G, long total, int nparts,
+                                       const float* __restrict__ hdr, float* __restrict__ pack, int nt) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < total) x3_bwx_pack_sym_one(W, H, m, G, nparts, hdr, pack, idx, nt);
+}
+
 __global__ void x3_bwx_pack_kernel(const float* __restrict__ W, int H, int Hp, int m, X3BwxGeom G, long total,
                                    int nparts, float* __restrict__ pack, int nt) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -325,8 +375,9 @@ struct X3PackJobs {
     float* fwd[X3_MAXJOBS];
     float* bwd[X3_MAXJOBS];
     float* fsym[X3_MAXJOBS];                 // folded forward pack of a level with Hp == m (null otherwise)
+    float* bsym[X3_MAXJOBS];                 // folded dX pack, likewise
     int H[X3_MAXJOBS], Hp[X3_MAXJOBS], m[X3_MAXJOBS], nparts[X3_MAXJOBS];
-    long nW[X3_MAXJOBS], fthreads[X3_MAXJOBS], bthreads[X3_MAXJOBS], sthreads[X3_MAXJOBS];
+    long nW[X3_MAXJOBS], fthreads[X3_MAXJOBS], bthreads[X3_MAXJOBS], sthreads[X3_MAXJOBS], bsthreads[X3_MAXJOBS];
     int nt;
     X3Geom fg[X3_MAXJOBS], sg[X3_MAXJOBS];
     X3BwxGeom bg[X3_MAXJOBS];
@@ -362,9 +413,13 @@ __global__ __launch_bounds__(1024) void x3_absmax_multi_kernel(const X3PackJobs 
 }
 
 __global__ __launch_bounds__(256) void x3_pack_multi_kernel(const X3PackJobs J) {
-    const int l = blockIdx.y / 3, dir = blockIdx.y - 3 * l;
+    const int l = blockIdx.y >> 2, dir = blockIdx.y & 3;
     const long stride = (long)gridDim.x * blockDim.x;
-    if (dir == 2) {
+    if (dir == 3) {
+        if (!J.bsym[l]) return;
+        for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.bsthreads[l]; idx += stride)
+            x3_bwx_pack_sym_one(J.W[l], J.H[l], J.m[l], J.bg[l], J.nparts[l], J.bwd[l], J.bsym[l], idx, J.nt);
+    } else if (dir == 2) {
         if (!J.fsym[l]) return;
         for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < J.sthreads[l]; idx += stride)
             x3_fwd_pack_sym_one(J.W[l], J.H[l], J.m[l], J.sg[l], J.nparts[l], J.fwd[l], J.fsym[l], idx, J.nt);
@@ -617,9 +672,17 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
     }
 }
 
-size_t x3_bwx_pack_elems(int H, int Hp, int m) {
+static size_t x3_bwx_pack_plain_elems(int H, int Hp, int m) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
     return (size_t)X3_HDR + ((size_t)g.NT * g.HBT + 2 * g.HBS) * (x3_terms() == 3 ? 512 : 256);
+}
+// as in the forward: a level with Hp == m carries the folded pack (m/2 tiles + two spare stages) behind the plain one
+static size_t x3_bwx_sym_offset(int H, int Hp, int m) { return (size_t)round_up((long)x3_bwx_pack_plain_elems(H, Hp, m), 4); }
+static long x3_bwx_sym_threads(const X3BwxGeom& g, int m) { return ((long)(m / 2) * g.HBT + 2 * g.HBS) * 64; }
+size_t x3_bwx_pack_elems(int H, int Hp, int m) {
+    if (!x3_fwd_has_sym(Hp, m)) return x3_bwx_pack_plain_elems(H, Hp, m);
+    const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
+    return x3_bwx_sym_offset(H, Hp, m) + (size_t)X3_HDR + (size_t)(x3_bwx_sym_threads(g, m) / 64) * (x3_terms() == 3 ? 512 : 256);
 }
 
 int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st) {
@@ -630,6 +693,11 @@ int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
     const long total = ((long)g.NT * g.HBT + 2 * g.HBS) * 64;
     hipLaunchKernelGGL(x3_bwx_pack_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, W, H, Hp, m, g, total,
                        x3_absmax_blocks(nW), pack, nt);
+    if (x3_fwd_has_sym(Hp, m)) {
+        const long ts = x3_bwx_sym_threads(g, m);
+        hipLaunchKernelGGL(x3_bwx_pack_sym_kernel, dim3(ceil_div(ts, 256)), dim3(256), 0, st, W, H, m, g, ts,
+                           x3_absmax_blocks(nW), pack, pack + x3_bwx_sym_offset(H, Hp, m), nt);
+    }
     return xdfm_check_launch("cin_bwd_pack (f16x3)");
 }
 
@@ -656,6 +724,8 @@ int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const fl
                    float* dxp, float* dx0, int flags, hipStream_t st) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: packed weights must be 16-byte aligned");
+    if (xp == x0 && x3_fwd_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0 && dxp != dx0)
+        return x3_level_bwd_x_sym(dOut, x0, pack + x3_bwx_sym_offset(H, Hp, m), H, m, N, g.HBT, x3_terms(), dxp, dx0, flags, st);
     if (x3_terms() == 1) {
         switch (g.HBT) {
             case 4: return launch_bwx3<4, 1>(dOut, xp, x0, pack, H, Hp, m, N, g, dxp, dx0, flags, st);
@@ -693,6 +763,8 @@ int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st) {
         J.fsym[l] = sym ? j.fwd_pack + x3_fwd_sym_offset(j.H, j.Hp, j.m) : nullptr;
         J.sthreads[l] = (long)J.sg[l].MB * J.sg[l].NSA * J.sg[l].MT * 64;
         J.bthreads[l] = ((long)J.bg[l].NT * J.bg[l].HBT + 2 * J.bg[l].HBS) * 64;
+        J.bsym[l] = l < L && j.bwd_pack && x3_fwd_has_sym(j.Hp, j.m) ? j.bwd_pack + x3_bwx_sym_offset(j.H, j.Hp, j.m) : nullptr;
+        J.bsthreads[l] = x3_bwx_sym_threads(J.bg[l], j.m);
         if (l < L) {
             if (J.fthreads[l] > maxthreads) maxthreads = J.fthreads[l];
             if (J.bthreads[l] > maxthreads) maxthreads = J.bthreads[l];
@@ -703,6 +775,6 @@ int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st) {
     if (J.nt == 3) hipLaunchKernelGGL(x3_absmax_multi_kernel, dim3(maxparts, L), dim3(1024), 0, st, J);
     int gx = ceil_div(maxthreads, 256);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(x3_pack_multi_kernel, dim3(gx, 3 * L), dim3(256), 0, st, J);
+    hipLaunchKernelGGL(x3_pack_multi_kernel, dim3(gx, 4 * L), dim3(256), 0, st, J);
     return xdfm_check_launch("cin_pack_all");
 }

@@ -146,6 +146,10 @@ int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
 int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
                    float* dxp, float* dx0, int flags, hipStream_t st);
 
+// level 0 with folded weights (cin_x3_bwx_sym.hip): the whole gradient goes to dx0, dxp is zero-filled if it is to be set
+int x3_level_bwd_x_sym(const float* dOut, const float* x0, const float* pack, int H, int m, long N, int HBT, int nt,
+                       float* dxp, float* dx0, int flags, hipStream_t st);
+
 // ---- dW geometry (cin_bwd.hip, cin_x3_bww.hip) ---------------------------------------------------
 #define BWW_NC 32         // columns per staged chunk
 static inline int bww_mt(int H) {
