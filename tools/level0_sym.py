@@ -92,4 +92,28 @@ for sym in (0, 1):
     err2 = d2.abs().max().item() / ref_g.abs().max().item()
     print("x3_sym=%d dX H=%d m=%d N=%d: %.1f us, max err / max |g| = %.2e, rms err / rms g = %.2e; accumulated twice: %.2e" % (
         sym, Hc, m, N, t, err, rms, err2), flush=True)
+
+# dW: sum_n dOut[h][n] x0[i][n] x0[j][n], all columns, fp64
+xd = x0.double()
+Zf = (xd[:, None, :] * xd[None, :, :]).reshape(m * m, N)
+ref_w = dOut.double() @ Zf.t()
+del Zf
+for sym in (0, 1):
+    _lib.set_option("x3_sym", sym)
+    ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, m, m, N), dtype=torch.float32, device=dev)
+    dW = torch.full((H, m * m), 7.0, device=dev)
+
+    def bww():
+        _lib.check(lib.xdfm_cin_level_bwd_w(dOut.data_ptr(), x0.data_ptr(), x0.data_ptr(), H, m, m, N, ws.data_ptr(),
+                                            dW.data_ptr(), st), "bwd_w")
+    t = timed(bww)
+    _lib.set_option("bww_phase", 2)
+    t2 = timed(bww)
+    _lib.set_option("bww_phase", 0)
+    bww()
+    d = dW.double() - ref_w
+    err = d.abs().max().item() / ref_w.abs().max().item()
+    rms = d.pow(2).mean().sqrt().item() / ref_w.pow(2).mean().sqrt().item()
+    print("x3_sym=%d dW H=%d m=%d N=%d: %.1f us (MFMA kernel alone %.1f us), max err / max |dW| = %.2e, rms err / rms = %.2e, "
+          "kernel %d" % (sym, H, m, N, t, t2, err, rms, _lib.get_option("last_bww_kernel")), flush=True)
 _lib.set_option("x3_sym", 1)

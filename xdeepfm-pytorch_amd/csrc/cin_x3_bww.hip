@@ -192,7 +192,11 @@ __device__ __forceinline__ void x3w_split_prod2(float a0, float b0, float a1, fl
 // wave tile as in cin_bwd_w_dma4_kernel: 32*MT rows of h x (32 i's of block iblk) x JT = 2 values of j
 // NW waves per workgroup share the staged dOut chunk: with 8 waves the planes are streamed by half as many
 // workgroups and half as many n-splits (slabs) are needed to fill the chip with one resident round
-template <int MT, int NW, int NT = 3>
+// SYM: level 0 (x_prev is x0) over the folded pair list.  dW[h][(i, j)] == dW[h][(j, i)], so only the pairs i <= j are
+// contracted: a wave tile is 32*MT rows of h x JT = 2 COMBINED column tiles; lane r of combined tile t (< m/2) is the
+// pair (i = r, j = t) for r <= t, (i = 31-r, j = m-1-t) for r >= 32-m+t (the dX kernel's tiling, cin_x3_bwx_sym.hip), both
+// factors read from the staged x0 block.  Slabs are compact, [t][h][r]; x3_bww_unpack_sym_kernel mirrors them into dW.
+template <int MT, int NW, int NT = 3, bool SYM = false>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
     const char* __restrict__ planes, long PB, const float* __restrict__ xp, const float* __restrict__ x0,
     const float* __restrict__ hdr, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
     const int wt0 = blockIdx.x * NW;
     const int hg = wt0 / TPH;
     const int tin = wt0 + wave - hg * TPH;
-    const bool active = tin < JP * IB;
+    const bool active = tin < JP * IB;           // SYM: IB == 1, JP = pairs of combined tiles
     const int jp = active ? tin / IB : 0;
     const int iblk = active ? tin - jp * IB : 0;
     const long NP = PB >> 2;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
     constexpr int WROWS = 32 + 8;                       // x_prev block + one 8-row group holding the x0 rows
     constexpr int BUF = (DROWS + NW * WROWS) * 128;     // bytes
     constexpr int ND_D = DROWS / (8 * NW);              // dOut-plane DMA instructions per wave (8 rows each)
-    constexpr int NDMA = ND_D + 4 + 1;
+    constexpr int NDMA = ND_D + 4 + (SYM ? 0 : 1);     // SYM: no x0 row group, both factors come from the x_prev (= x0) block
     static_assert(DROWS % (8 * NW) == 0, "every wave stages the same number of dOut rows");
 
     const int lrow = lane >> 3, pc = lane & 7;
@@ -251,13 +255,28 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
 
     // per-lane scale of the B operand: sxp[i] * sx0[j]
     float fz[JT];
-    {
+    int ri[JT], rj[JT];                          // SYM: the lane's pair in each combined tile (rows of the staged x0 block)
+    if constexpr (SYM) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int t = jp * JT + jt;
+            int i = -1, j = 0;
+            if (active && t < m / 2) {
+                if (r <= t) { i = r; j = t; }
+                else if (31 - r <= m - 1 - t) { i = 31 - r; j = m - 1 - t; }
+            }
+            fz[jt] = i >= 0 ? hdr[Hpad + i] * hdr[Hpad + IPAD + j] : 0.f;
+            ri[jt] = i >= 0 ? i : 0;
+            rj[jt] = j;
+        }
+    } else {
         const int i = iblk * 32 + r;
         const float sx = hdr[Hpad + (i < IPAD ? i : 0)];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             const int j = jp * JT + jt;
             fz[jt] = (i < Hp && j < m) ? sx * hdr[Hpad + IPAD + (j < m ? j : 0)] : 0.f;
+            ri[jt] = rj[jt] = 0;
         }
     }
 
@@ -279,14 +298,26 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
         for (int nb = 0; nb < 2; ++nb) {
             // B operand: Z[(i_r, j)][n = 16 nb + 8 hh + t], t < 8
             const int q0 = nb * 4 + 2 * hh;
-            const float4 xa = *reinterpret_cast<const float4*>(xS + (r * 8 + (q0 ^ sr)) * 16);
-            const float4 xb = *reinterpret_cast<const float4*>(xS + (r * 8 + ((q0 + 1) ^ sr)) * 16);
-            const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+            float4 xa, xb;
+            if constexpr (!SYM) {
+                xa = *reinterpret_cast<const float4*>(xS + (r * 8 + (q0 ^ sr)) * 16);
+                xb = *reinterpret_cast<const float4*>(xS + (r * 8 + ((q0 + 1) ^ sr)) * 16);
+            }
             h8 bh[JT], bl[JT];
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
-                const float4 za = *reinterpret_cast<const float4*>(zS + (jt * 8 + q0) * 16);
-                const float4 zb = *reinterpret_cast<const float4*>(zS + (jt * 8 + q0 + 1) * 16);
+                float4 za, zb;
+                if constexpr (SYM) {
+                    const int si = swz(ri[jt]), sj = swz(rj[jt]);
+                    xa = *reinterpret_cast<const float4*>(xS + (ri[jt] * 8 + (q0 ^ si)) * 16);
+                    xb = *reinterpret_cast<const float4*>(xS + (ri[jt] * 8 + ((q0 + 1) ^ si)) * 16);
+                    za = *reinterpret_cast<const float4*>(xS + (rj[jt] * 8 + (q0 ^ sj)) * 16);
+                    zb = *reinterpret_cast<const float4*>(xS + (rj[jt] * 8 + ((q0 + 1) ^ sj)) * 16);
+                } else {
+                    za = *reinterpret_cast<const float4*>(zS + (jt * 8 + q0) * 16);
+                    zb = *reinterpret_cast<const float4*>(zS + (jt * 8 + q0 + 1) * 16);
+                }
+                const float xv[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
                 const float zv[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
 #pragma unroll
                 for (int t2 = 0; t2 < 4; ++t2) {
@@ -344,6 +375,20 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
     if (!active) return;
     const int i = iblk * 32 + r;
     float* __restrict__ dst = dWt + (long)blockIdx.y * slab_stride;
+    if constexpr (SYM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const int t = jp * JT + jt;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int h = hg * 32 * MT + mt * 32 + frag_row(q, hh);
+                    if (t < m / 2) dst[((long)t * Hpad + h) * 32 + r] = acc[mt][jt][q];
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -381,6 +426,36 @@ __global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const float*
     dW[(long)h * ((long)Hp * m) + (long)i * m + j] = acc * (1.f / sd) * (1.f / sx) * (1.f / sz);
 }
 
+// folded level 0: dW[h][i*m+j] = dW[h][j*m+i] = (sum over n-splits of slab[split][t][h][r]) / (sD[h] * sx0[i] * sx0[j]),
+// (i, j) the pair of lane r in combined tile t.  One thread per slab element (coalesced reads of every split), two
+// 4-byte stores.
+__global__ void x3_bww_unpack_sym_kernel(const float* __restrict__ dWt, const float* __restrict__ hdr, int H, int m,
+                                         int Hpad, int IPAD, int nslab, long slab_stride, float* __restrict__ dW) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)(m / 2) * Hpad * 32) return;
+    const int r = (int)(idx & 31);
+    const int h = (int)((idx >> 5) % Hpad), t = (int)((idx >> 5) / Hpad);
+    int i, j;
+    if (r <= t) { i = r; j = t; }
+    else if (31 - r <= m - 1 - t) { i = 31 - r; j = m - 1 - t; }
+    else return;
+    if (h >= H) return;
+    float acc = 0.f;
+    int k = 0;
+    for (; k + 8 <= nslab; k += 8) {                    // 8 slab loads in flight; the sum keeps its fixed order
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = dWt[(long)(k + q) * slab_stride + idx];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc += v[q];
+    }
+    for (; k < nslab; ++k) acc += dWt[(long)k * slab_stride + idx];
+    const float v = acc * (1.f / hdr[h]) * (1.f / hdr[Hpad + i]) * (1.f / hdr[Hpad + IPAD + j]);
+    float* __restrict__ row = dW + (long)h * ((long)m * m);
+    row[i * m + j] = v;
+    if (i != j) row[j * m + i] = v;
+}
+
 // ---------------------------------------------------------------------------------------------
 static inline int x3_bww_waves() { return xdfm_opt(OPT_X3_WAVES) == 4 ? 4 : 8; }
 
@@ -401,17 +476,44 @@ static BwwGeom x3_bww_geometry(int H, int Hp, int m, long N, int NW) {
     return g;
 }
 
+// folded level 0: JP = pairs of combined tiles, compact slabs [m/2][Hpad][32]
+static BwwGeom x3_bww_geometry_sym(int H, int m, long N, int NW) {
+    BwwGeom g = bww_geometry(H, m, m, N);
+    g.JP = ceil_div(m / 2, BWW_JT);
+    g.TPH = (int)round_up((long)g.JP, NW);
+    g.gx = g.HG * g.TPH / NW;
+    int nsplit = xdfm_opt(OPT_BWW_NSPLIT);
+    const int max_split = ceil_div(N, BWW_NC);
+    const int slots = NW == 8 ? 256 : 512;
+    if (nsplit <= 0) nsplit = slots / g.gx > 0 ? slots / g.gx : 1;
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > 65535) nsplit = 65535;
+    g.n_per_split = round_up(ceil_div(N, nsplit), BWW_NC);
+    g.nsplit = ceil_div(N, g.n_per_split);
+    g.slab = (long)(m / 2) * g.Hpad * 32;
+    return g;
+}
+static bool x3_bww_has_sym(int Hp, int m) { return Hp == m && x3_sym_m(m); }
+
 size_t x3_bww_ws_elems(int H, int Hp, int m, long N) {
     const BwwGeom g = x3_bww_geometry(H, Hp, m, N, x3_bww_waves());
     const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);
-    return (size_t)w.hdr + (size_t)w.parts + (size_t)w.planes + (size_t)g.slab * g.nsplit;
+    size_t slabs = (size_t)g.slab * g.nsplit;
+    if (x3_bww_has_sym(Hp, m)) {            // whether the level IS level 0 (x_prev == x0) is known at launch only
+        const BwwGeom gs = x3_bww_geometry_sym(H, m, N, x3_bww_waves());
+        const size_t s2 = (size_t)gs.slab * gs.nsplit;
+        if (s2 > slabs) slabs = s2;
+    }
+    return (size_t)w.hdr + (size_t)w.parts + (size_t)w.planes + slabs;
 }
 
 int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
                    float* dW, hipStream_t st) {
     const int NW = x3_bww_waves();
     BwwGeom g = x3_bww_geometry(H, Hp, m, N, NW);
-    const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);
+    const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);          // header, partial maxima, planes: the same in both tilings
+    const bool sym = xp == x0 && x3_bww_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0;
+    if (sym) g = x3_bww_geometry_sym(H, m, N, NW);
     if ((((size_t)ws) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_w: workspace must be 16-byte aligned");
     float* hdr = ws;
     float* parts = ws + w.hdr;
@@ -444,13 +546,24 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
 #define BWW_LAUNCH(NWV, NTV) \
     hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, NWV, NTV>), dim3(g.gx, g.nsplit), dim3(64 * NWV), lds, st, planes, w.NP * 4, xp, \
                        x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab)
-    if (NW == 8) { if (nt == 3) BWW_LAUNCH(8, 3); else BWW_LAUNCH(8, 1); }
+#define BWW_LAUNCH_SYM(NWV, NTV) \
+    hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, NWV, NTV, true>), dim3(g.gx, g.nsplit), dim3(64 * NWV), lds, st, planes, w.NP * 4, xp, \
+                       x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab)
+    if (sym) {
+        if (NW == 8) { if (nt == 3) BWW_LAUNCH_SYM(8, 3); else BWW_LAUNCH_SYM(8, 1); }
+        else { if (nt == 3) BWW_LAUNCH_SYM(4, 3); else BWW_LAUNCH_SYM(4, 1); }
+    } else if (NW == 8) { if (nt == 3) BWW_LAUNCH(8, 3); else BWW_LAUNCH(8, 1); }
     else { if (nt == 3) BWW_LAUNCH(4, 3); else BWW_LAUNCH(4, 1); }
+#undef BWW_LAUNCH_SYM
 #undef BWW_LAUNCH
     rc = xdfm_check_launch("cin_level_bwd_w (f16x3)");
     if (rc) return rc;
     }
-    if (phase == 0 || phase == 3) {
+    if ((phase == 0 || phase == 3) && sym) {
+    hipLaunchKernelGGL(x3_bww_unpack_sym_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, slabs, hdr, H, m,
+                       g.Hpad, g.IPAD, g.nsplit, g.slab, dW);
+    rc = xdfm_check_launch("cin_level_bwd_w unpack (folded level 0)");
+    } else if (phase == 0 || phase == 3) {
     hipLaunchKernelGGL(x3_bww_unpack_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, slabs, hdr, H, Hp, m, g.Hpad,
                        g.IPAD, g.nsplit, g.slab, dW);
     rc = xdfm_check_launch("cin_level_bwd_w unpack (f16x3)");
