@@ -171,8 +171,8 @@ def cpu_baseline(cfg, vocab, rows, steps):
                        % (steps, rows, dt / steps))
 
 
-PMC_KERNEL = {"cin_level_bwd_x": "cin_bwd_x3_kernel", "cin_level_bwd_w": "cin_bwd_w_x3_kernel",
-              "cin_level_fwd": "cin_fwd_x3_kernel"}
+PMC_KERNEL = {"cin_level_bwd_x": ("cin_bwd_x3_kernel", "cin_bwd_x3_sym_kernel"), "cin_level_bwd_w": ("cin_bwd_w_x3_kernel",),
+              "cin_level_fwd": ("cin_fwd_x3_kernel",)}
 
 
 def pmc_traffic(bracket, workload, math_mode):
@@ -402,7 +402,9 @@ def main():
             roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1),
                         unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
                         launches=n, avg_ms=round(secs / n * 1e3, 4),
-                        note="fp32-equivalent FLOPs (2*H*Hp*m*N per launch); " + CIN_MATH[math_mode][2])
+                        note="fp32-equivalent FLOPs of the reference's contraction (2*H*Hp*m*N per launch); level 0 "
+                             "(x_prev is x0) contracts over the pairs i <= j with folded weights and issues about half (50-54 %) "
+                             "of the MFMAs counted here for it; " + CIN_MATH[math_mode][2])
             roof.update(pmc_traffic(name, args.workload, math_mode))
         kernels = {}
         calls_per_step = {k: v[2] / prof_steps for k, v in per_kernel.items()}
