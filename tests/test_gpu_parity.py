@@ -159,6 +159,74 @@ def test_cin_vs_oracle_random(B, m, D, ls, cin_math):
             gclose(c.bias.grad, Bs[i].grad.numpy(), "db%d" % i)
 
 
+@pytest.mark.parametrize("math", [1, 2])
+@pytest.mark.parametrize("H,m,N", [(256, 26, 4096 + 48), (200, 22, 1000), (40, 26, 260)])
+def test_cin_level0_folded_contraction_matches_full_grid(H, m, N, math):
+    """Level 0 of the CIN multiplies x0 with itself (deepctr/layers/interaction.py:218-224 with hidden_nn_layers[-1] is
+    x0), so Z[(i, j)] == Z[(j, i)] and the f16x3 / bf16 kernels contract over the pairs i <= j with the folded weights
+    W(i, j) + W(j, i) (option x3_sym, default on; field counts 22 and 26).  Through the C ABI, against the fp64
+    contraction: forward, dX (set and accumulate), dW; the folded kernels must have run (probe last_sym), must be at
+    least as close to fp64 as the full-grid kernels within a factor 1.5, and dW must be exactly symmetric."""
+    from xdfm_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(H + m)
+    W = torch.randn(H, m * m, device=dev) * 0.05
+    x0 = torch.randn(m, N, device=dev)
+    bias = torch.randn(H, device=dev) * 0.1
+    dOut = torch.randn(H, N, device=dev)
+    xd = x0.double().requires_grad_(True)
+    Z = (xd[:, None, :] * xd[None, :, :]).reshape(m * m, N)
+    pre = W.double() @ Z + bias.double()[:, None]
+    (pre * dOut.double()).sum().backward()
+    want_out, want_g, want_w = torch.relu(pre.detach()), xd.grad, dOut.double() @ Z.detach().t()
+    old_math, old_sym = _lib.get_option("cin_math"), _lib.get_option("x3_sym")
+    errs = {}
+    try:
+        _lib.set_option("cin_math", math)
+        for sym in (0, 1):
+            _lib.set_option("x3_sym", sym)
+            _lib.set_option("last_sym", 0)
+            pack = torch.empty(lib.xdfm_cin_fwd_pack_elems(H, m, m), dtype=torch.float32, device=dev)
+            _lib.check(lib.xdfm_cin_fwd_pack(W.data_ptr(), H, m, m, pack.data_ptr(), st), "pack")
+            out = torch.zeros(H, N, device=dev)
+            _lib.check(lib.xdfm_cin_level_fwd(x0.data_ptr(), x0.data_ptr(), pack.data_ptr(), bias.data_ptr(), H, m, m, N, 1,
+                                              out.data_ptr(), st), "fwd")
+            used = _lib.get_option("last_fwd_kernel") == math
+            wz = torch.empty(lib.xdfm_cin_bwd_pack_elems(H, m, m), dtype=torch.float32, device=dev)
+            _lib.check(lib.xdfm_cin_bwd_pack(W.data_ptr(), H, m, m, wz.data_ptr(), st), "bwd pack")
+            dxp, dx0 = torch.full((m, N), 3.0, device=dev), torch.full((m, N), 5.0, device=dev)
+            _lib.check(lib.xdfm_cin_level_bwd_x_ex(dOut.data_ptr(), x0.data_ptr(), x0.data_ptr(), wz.data_ptr(), H, m, m, N,
+                                                   dxp.data_ptr(), dx0.data_ptr(), 3, st), "bwd_x")
+            g1 = (dxp + dx0).double()
+            _lib.check(lib.xdfm_cin_level_bwd_x_ex(dOut.data_ptr(), x0.data_ptr(), x0.data_ptr(), wz.data_ptr(), H, m, m, N,
+                                                   dxp.data_ptr(), dx0.data_ptr(), 0, st), "bwd_x")
+            g2 = (dxp + dx0).double()
+            ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, m, m, N), dtype=torch.float32, device=dev)
+            dW = torch.full((H, m * m), 7.0, device=dev)
+            _lib.check(lib.xdfm_cin_level_bwd_w(dOut.data_ptr(), x0.data_ptr(), x0.data_ptr(), H, m, m, N, ws.data_ptr(),
+                                                dW.data_ptr(), st), "bwd_w")
+            if _lib.get_option("last_fwd_kernel") != math or _lib.get_option("last_bwx_kernel") != math:
+                pytest.skip("no f16x3 / bf16 kernel for this shape")          # (bf16 needs H > 64)
+            x3_dw = _lib.get_option("last_bww_kernel") == math
+            assert used
+            assert _lib.get_option("last_sym") == ((3 | (4 if x3_dw else 0)) if sym else 0)
+
+            def rel(got, want):
+                return float((got.double() - want).abs().max() / want.abs().max())
+            errs[sym] = (rel(out, want_out), rel(g1, want_g), rel(g2, 2 * want_g), rel(dW, want_w))
+            if sym and x3_dw:
+                d3 = dW.view(H, m, m)
+                assert torch.equal(d3, d3.transpose(1, 2))
+    finally:
+        _lib.set_option("cin_math", old_math)
+        _lib.set_option("x3_sym", old_sym)
+    tol = 2e-6 if math == 1 else 1e-2
+    for a, b in zip(errs[1], errs[0]):
+        assert a < tol and a < 1.5 * b + 1e-7, (errs[1], errs[0])
+
+
 @pytest.mark.parametrize("B,m,D,ls,act", [
     (96, 22, 32, (512, 256, 256, 128), "linear"),      # BASELINE config 5 layer sizes (Avazu shape), gradients checked
     (96, 22, 32, (512, 256, 256, 128), "relu"),

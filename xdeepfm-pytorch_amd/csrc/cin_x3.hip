@@ -241,7 +241,9 @@ int x3_level_fwd(const float* xp, const float* x0, const float* pack, const floa
     act |= ((xdfm_opt(OPT_DBG) >> 6) & 255) << 8;     // timing experiments (results become wrong): see the kernels' `dbg`
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd: packed weights must be 16-byte aligned");
     if (nt != 3 && g.MT < 4) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd (bf16): no kernel for MT=%d", g.MT);
-    if (xp == x0 && x3_fwd_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0)
+    const bool sym = xp == x0 && x3_fwd_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0;
+    xdfm_opt_note(OPT_LAST_SYM, (xdfm_opt(OPT_LAST_SYM) & ~1) | (sym ? 1 : 0));
+    if (sym)
         return x3_level_fwd_sym(x0, pack + x3_fwd_sym_offset(H, Hp, m), bias, H, m, N, x3_fwd_geom_sym(H, m), nt, act, out, st);
     if (m == 26) return X3_FWD_DISPATCH_M(26);
     if (m == 22) return X3_FWD_DISPATCH_M(22);
@@ -724,7 +726,9 @@ int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const fl
                    float* dxp, float* dx0, int flags, hipStream_t st) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: packed weights must be 16-byte aligned");
-    if (xp == x0 && x3_fwd_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0 && dxp != dx0)
+    const bool sym = xp == x0 && x3_fwd_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0 && dxp != dx0;
+    xdfm_opt_note(OPT_LAST_SYM, (xdfm_opt(OPT_LAST_SYM) & ~2) | (sym ? 2 : 0));
+    if (sym)
         return x3_level_bwd_x_sym(dOut, x0, pack + x3_bwx_sym_offset(H, Hp, m), H, m, N, g.HBT, x3_terms(), dxp, dx0, flags, st);
     if (x3_terms() == 1) {
         switch (g.HBT) {

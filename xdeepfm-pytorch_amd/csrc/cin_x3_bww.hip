@@ -514,6 +514,7 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);          // header, partial maxima, planes: the same in both tilings
     const bool sym = xp == x0 && x3_bww_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0;
     if (sym) g = x3_bww_geometry_sym(H, m, N, NW);
+    xdfm_opt_note(OPT_LAST_SYM, (xdfm_opt(OPT_LAST_SYM) & ~4) | (sym ? 4 : 0));
     if ((((size_t)ws) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_w: workspace must be 16-byte aligned");
     float* hdr = ws;
     float* parts = ws + w.hdr;

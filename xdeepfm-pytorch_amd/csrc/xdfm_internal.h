@@ -29,6 +29,7 @@ enum {
     OPT_LAST_FWD,        // read-only probes: arithmetic of the kernel the last xdfm_cin_level_fwd / _bwd_x / _bwd_w call
     OPT_LAST_BWX,        //   launched: 0 = v_mfma_f32_32x32x2_f32, 1 = f16x3, 2 = bf16 (tests assert which kernel ran)
     OPT_LAST_BWW,
+    OPT_LAST_SYM,        // read-only probe: bit 0 / 1 / 2 = the last f16x3 / bf16 forward / dX / dW launch ran the folded level-0 kernel
     OPT_X3_SYM,          // 1 (default) = level 0 (x_prev is x0) contracts over the pairs i <= j with folded weights; 0 = full (i, j) grid
     OPT_COUNT
 };
