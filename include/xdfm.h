@@ -71,6 +71,14 @@ int xdfm_device_count(void);                /* <0: HIP error code negated */
  *      its own: 2e-2 (outputs) / 4e-2 (gradients) of a tensor's largest magnitude against the fp32 reference,
  *      measured 3e-3 / 8e-3 (tests/test_gpu_parity.py::test_cin_bf16_mfma_path_vs_fp32_oracle).  Kernels exist for
  *      H > 64 (forward, dW), 32 < H <= 256 per call (dX), m in {22, 26}; other shapes run mode 0. */
+/* "x3_sym" (default 1): level 0 of a CIN, where x_prev IS x0 (the calls get xp == x0; interaction.py:214-224), is
+ * symmetric in (i, j).  With x3_sym != 0 the f16x3 / bf16 kernels of that level contract over the pairs i <= j with the
+ * folded weights W(i,j) + W(j,i) -- about half the MFMAs; fields m in {22, 26}.  The packs of every level with Hp == m
+ * carry the folded layout behind the plain one (the *_pack_elems sizes include it whatever the option says), and which
+ * one a launch reads is decided by xp == x0.  Results: forward and dW as before up to rounding (dW exactly symmetric);
+ * dX puts the WHOLE gradient of the level into dx0 and zero-fills dxp when XDFM_BWX_SET_DXP is given (leaves it alone
+ * otherwise) -- with xp == x0 only the sum dxp + dx0 was ever meaningful.  Probe "last_sym": bit 0 / 1 / 2 = the last
+ * f16x3 / bf16 forward / dX / dW launch ran the folded kernel. */
 /* read-only probes (xdfm_get_option): "last_fwd_kernel", "last_bwx_kernel", "last_bww_kernel" = arithmetic of the kernel
  * the last xdfm_cin_level_fwd / _bwd_x / _bwd_w call launched (0 f32mfma, 1 f16x3, 2 bf16; -1 before the first call):
  * a shape without a kernel in the selected mode runs mode 0, and the tests assert which one ran. */
@@ -180,7 +188,8 @@ int xdfm_cin_dout_det(const float* A, int H, int B, int D, int act,
 /* dx_prev[i][n] += sum_j dZ[(i,j)][n] * x0[j][n];  dx0[j][n] += sum_i dZ[(i,j)][n] * x_prev[i][n]
  * with dZ = W^T dOut recomputed tile by tile.  dxp [Hp][N] and dx0 [m][N] are ACCUMULATED into
  * (caller zero-initialises); dxp and dx0 must NOT alias (for level 0, where x_prev is x0, pass a
- * scratch dxp and add it to dx0 afterwards).  H <= 256 rows of the contraction per call. */
+ * scratch dxp and add it to dx0 afterwards: how the level's gradient is divided between the two is then up to the
+ * kernel -- see option "x3_sym").  H <= 256 rows of the contraction per call. */
 size_t xdfm_cin_bwd_pack_elems(int H, int Hp, int m);
 int xdfm_cin_bwd_pack(const float* W, int H, int Hp, int m, float* Wz, void* stream);
 int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* Wz,
