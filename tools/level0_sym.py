@@ -1,6 +1,6 @@
 """Level 0 of the CIN (x_prev is x0) with and without the folded pair list (library option "x3_sym"): time per launch by
 events and the error against an fp64 contraction, forward / dX / dW.
-    python tools/level0_sym.py [H m N] [math=2]"""
+    python tools/level0_sym.py [H m N] [math=2] [opt=name:value ...]"""
 import os
 import sys
 
@@ -17,6 +17,10 @@ nums = [a for a in sys.argv[1:] if "=" not in a]
 H, m, N = (int(v) for v in nums[:3]) if len(nums) >= 3 else (256, 26, 65536)
 if math:
     _lib.set_option("cin_math", math[0])          # 1 = f16x3 (default), 2 = bf16
+for a in sys.argv[1:]:
+    if a.startswith("opt="):                      # any library option, e.g. opt=x3_fwd_mt:4 opt=x3_waves:4
+        k, v = a[4:].split(":")
+        _lib.set_option(k, int(v))
 st = torch.cuda.current_stream().cuda_stream
 torch.manual_seed(0)
 W = torch.randn(H, m * m, device=dev) * 0.05

@@ -812,6 +812,7 @@ int xdfm_cin_level_bwd_x_ex(const float* dOut, const float* xp, const float* x0,
     hipStream_t st = (hipStream_t)stream;
     if (x3_bwx_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_BWX, xdfm_opt(OPT_CIN_MATH)); return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st); }
     xdfm_opt_note(OPT_LAST_BWX, 0);
+    xdfm_opt_note(OPT_LAST_SYM, xdfm_opt(OPT_LAST_SYM) & ~2);
     switch (bwx_hs4(H)) {
         case 1: return launch_bwd_x<1>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
         case 2: return launch_bwd_x<2>(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st);
@@ -840,6 +841,7 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, in
     hipStream_t st = (hipStream_t)stream;
     if (x3_bww_usable(dOut, xp, x0, H, N)) { xdfm_opt_note(OPT_LAST_BWW, xdfm_opt(OPT_CIN_MATH)); return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, st); }
     xdfm_opt_note(OPT_LAST_BWW, 0);
+    xdfm_opt_note(OPT_LAST_SYM, xdfm_opt(OPT_LAST_SYM) & ~4);
     const int phase = xdfm_opt(OPT_BWW_PHASE);            // fp32 kernels: the whole call counts as phase 2
     if (phase == 1 || phase == 3) return XDFM_OK;
     switch (bww_mt(H)) {

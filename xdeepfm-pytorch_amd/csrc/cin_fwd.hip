@@ -457,6 +457,7 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
     hipStream_t st = (hipStream_t)stream;
     if (x3_fwd_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_FWD, xdfm_opt(OPT_CIN_MATH)); return x3_level_fwd(xp, x0, Wf, bias, H, Hp, m, N, act, out, st); }
     xdfm_opt_note(OPT_LAST_FWD, 0);
+    xdfm_opt_note(OPT_LAST_SYM, xdfm_opt(OPT_LAST_SYM) & ~1);
     const int nf = xdfm_opt(OPT_FWD_NF) == 2 ? 2 : 1;
     switch (fwd_mt(H)) {
         case 1: return launch_fwd<1, 1>(xp, x0, Wf, bias, H, Hp, m, N, act, out, st);

@@ -71,29 +71,48 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_sym_kernel(
             if (nok) dxp[(long)i * N + n] = 0.f;
     }
 
-    // B operand: dOut[h][n] for all h of this launch, column-scaled and split, in registers
-    float dmax = 0.f;
-    if constexpr (NT == 3) {
-        dmax = x3_col_absmax(dOut + nc, N, hh, H);
-        dmax = fmaxf(dmax, __shfl_xor(dmax, 32)) * nmask;
-    }
-    const float sD = NT == 3 ? x3_pow2_scale(dmax, 15) : 1.f;
+    // B operand: dOut[h][n] for all h of this launch, column-scaled and split, in registers.  ONE read of dOut: the lane's
+    // 8*HBT values (8*HBT independent loads in flight) are held raw while the column maximum is formed, then scaled
+    // and split in place (a separate maximum pass read the wave's columns of dOut twice: 67 of 152 MB fetched per launch
+    // at level 0 of config 2)
     h8 bh[HBT], bl[NT == 3 ? HBT : 1];
+    float sD = 1.f;
+    {
+        float raw[8 * HBT];
 #pragma unroll
-    for (int hb = 0; hb < HBT; ++hb) {
+        for (int hb = 0; hb < HBT; ++hb)
 #pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) {
-            const int h = 16 * hb + 8 * hh + 2 * t2;
-            const float v0 = dOut[(long)(h < H ? h : H - 1) * N + nc] * ((h < H) ? sD * nmask : 0.f);
-            const float v1 = dOut[(long)(h + 1 < H ? h + 1 : H - 1) * N + nc] * ((h + 1 < H) ? sD * nmask : 0.f);
-            h2 hi, lo;
-            if constexpr (NT == 3) {
-                x3_split2(v0, v1, hi, lo);
-                bl[hb][2 * t2] = lo.x; bl[hb][2 * t2 + 1] = lo.y;
-            } else {
-                hi = x3_bf16_pair(v0, v1);
+            for (int t = 0; t < 8; ++t) {
+                const int h = 16 * hb + 8 * hh + t;
+                raw[8 * hb + t] = dOut[(long)(h < H ? h : H - 1) * N + nc];
             }
-            bh[hb][2 * t2] = hi.x; bh[hb][2 * t2 + 1] = hi.y;
+        float dmax = 0.f;
+#pragma unroll
+        for (int hb = 0; hb < HBT; ++hb)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int h = 16 * hb + 8 * hh + t;
+                raw[8 * hb + t] *= (h < H) ? nmask : 0.f;
+                dmax = fmaxf(dmax, fabsf(raw[8 * hb + t]));
+            }
+        if constexpr (NT == 3) {                                      // bf16 operands need no range fitting
+            dmax = fmaxf(dmax, __shfl_xor(dmax, 32));
+            sD = x3_pow2_scale(dmax, 15);
+        }
+#pragma unroll
+        for (int hb = 0; hb < HBT; ++hb) {
+#pragma unroll
+            for (int t2 = 0; t2 < 4; ++t2) {
+                const float v0 = raw[8 * hb + 2 * t2] * sD, v1 = raw[8 * hb + 2 * t2 + 1] * sD;
+                h2 hi, lo;
+                if constexpr (NT == 3) {
+                    x3_split2(v0, v1, hi, lo);
+                    bl[hb][2 * t2] = lo.x; bl[hb][2 * t2 + 1] = lo.y;
+                } else {
+                    hi = x3_bf16_pair(v0, v1);
+                }
+                bh[hb][2 * t2] = hi.x; bh[hb][2 * t2 + 1] = hi.y;
+            }
         }
     }
     const float inv = NT == 3 ? (1.f / sD) * pack[1] : 1.f;      // removes both scales from dZ'

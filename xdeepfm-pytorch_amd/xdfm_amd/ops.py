@@ -476,8 +476,9 @@ class CINStack(torch.autograd.Function):
                     _ptr(dOc), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m, N, _ptr(dxp), _ptr(dx0), flags, _stream())),
                     "cin_level_bwd_x")
                 dx0_set = True
-            if l == 0:
-                dx0 += dxp                               # x_prev of level 0 is x0 itself
+            if l == 0 and not (_lib.get_option("last_sym") & 2):
+                dx0 += dxp                               # x_prev of level 0 is x0 itself (the folded dX kernel has put the
+                #                                          whole gradient into dx0 already: include/xdfm.h, option x3_sym)
             dhid = dxp
         return (dx0, None, None, None, None, None, None) + tuple(grads)
 
