@@ -21,8 +21,9 @@ static int g_opts[OPT_COUNT] = {
     /* OPT_LAST_BWW */ -1,
     /* OPT_LAST_SYM */ 0,
     /* OPT_X3_SYM */ 1,
+    /* OPT_BWW_XCD */ 1,
 };
-static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math", "x3_fwd_mt", "x3_bwx_rows", "x3_waves", "bww_phase", "adam_bx", "last_fwd_kernel", "last_bwx_kernel", "last_bww_kernel", "last_sym", "x3_sym"};
+static const char* const g_opt_names[OPT_COUNT] = {"fwd_nf", "bww_nsplit", "bww_slab", "bww_mt", "dbg", "cin_math", "x3_fwd_mt", "x3_bwx_rows", "x3_waves", "bww_phase", "adam_bx", "last_fwd_kernel", "last_bwx_kernel", "last_bww_kernel", "last_sym", "x3_sym", "bww_xcd"};
 
 int xdfm_fail(int code, const char* fmt, ...) {
     va_list ap;

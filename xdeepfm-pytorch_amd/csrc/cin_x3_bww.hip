@@ -200,20 +200,33 @@ template <int MT, int NW, int NT = 3, bool SYM = false>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
     const char* __restrict__ planes, long PB, const float* __restrict__ xp, const float* __restrict__ x0,
     const float* __restrict__ hdr, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
-    int IPAD, float* __restrict__ dWt, long slab_stride) {
+    int IPAD, float* __restrict__ dWt, long slab_stride, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int JT = 2;
+    // The gridDim.x workgroups of one n-split stream the same dOut planes.  Workgroups are dealt to the 8 XCDs round
+    // robin in launch order, so with the plain (x, y) indexing a split's workgroups sit on 7-8 different XCDs and every
+    // L2 fetches the planes for itself (343 MB fetched per launch against 74 MB of operands at level 1 of config 2).
+    // Remapped: XCD k runs a contiguous range of the (split, x) list, i.e. whole splits.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (xcd_remap) {
+        const int total = gridDim.x * gridDim.y;
+        const int L = blockIdx.y * gridDim.x + blockIdx.x, k = L & 7, slot = L >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int Lr = (k < r ? k * (q + 1) : r * (q + 1) + (k - r) * q) + slot;
+        by = Lr / (int)gridDim.x;
+        bx = Lr - by * (int)gridDim.x;
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int wt0 = blockIdx.x * NW;
+    const int wt0 = bx * NW;
     const int hg = wt0 / TPH;
     const int tin = wt0 + wave - hg * TPH;
     const bool active = tin < JP * IB;           // SYM: IB == 1, JP = pairs of combined tiles
     const int jp = active ? tin / IB : 0;
     const int iblk = active ? tin - jp * IB : 0;
     const long NP = PB >> 2;
-    const long n_begin = (long)blockIdx.y * n_per_split;
+    const long n_begin = (long)by * n_per_split;
     const long n_end = (n_begin + n_per_split < NP) ? n_begin + n_per_split : NP;   // multiples of 32
     const int nch = (int)((n_end - n_begin) / BWW_NC);
 
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
 
     if (!active) return;
     const int i = iblk * 32 + r;
-    float* __restrict__ dst = dWt + (long)blockIdx.y * slab_stride;
+    float* __restrict__ dst = dWt + (long)by * slab_stride;
     if constexpr (SYM) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -544,12 +557,13 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     }
     if (phase == 0 || phase == 2) {
     const size_t lds = (size_t)2 * (32 * 4 + NW * (32 + 8)) * 128;
+    const int xcd = xdfm_opt(OPT_BWW_XCD) != 0 ? 1 : 0;
 #define BWW_LAUNCH(NWV, NTV) \
     hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, NWV, NTV>), dim3(g.gx, g.nsplit), dim3(64 * NWV), lds, st, planes, w.NP * 4, xp, \
-                       x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab)
+                       x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab, xcd)
 #define BWW_LAUNCH_SYM(NWV, NTV) \
     hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, NWV, NTV, true>), dim3(g.gx, g.nsplit), dim3(64 * NWV), lds, st, planes, w.NP * 4, xp, \
-                       x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab)
+                       x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab, xcd)
     if (sym) {
         if (NW == 8) { if (nt == 3) BWW_LAUNCH_SYM(8, 3); else BWW_LAUNCH_SYM(8, 1); }
         else { if (nt == 3) BWW_LAUNCH_SYM(4, 3); else BWW_LAUNCH_SYM(4, 1); }

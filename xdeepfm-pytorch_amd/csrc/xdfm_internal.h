@@ -31,6 +31,7 @@ enum {
     OPT_LAST_BWW,
     OPT_LAST_SYM,        // read-only probe: bit 0 / 1 / 2 = the last f16x3 / bf16 forward / dX / dW launch ran the folded level-0 kernel
     OPT_X3_SYM,          // 1 (default) = level 0 (x_prev is x0) contracts over the pairs i <= j with folded weights; 0 = full (i, j) grid
+    OPT_BWW_XCD,         // 1 (default) = the f16x3 / bf16 dW kernel keeps the workgroups of an n-split on one XCD; 0 = launch order
     OPT_COUNT
 };
 
