@@ -167,6 +167,7 @@ def test_row_parallel_four_ranks_with_cold_rows_gpu(tmp_path, monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     monkeypatch.setenv("XDFM_TEST_BIG_VOCAB", "1")
+    monkeypatch.setenv("XDFM_ADAM_DEFERRED", "1")        # tables this small take the dense sweep by default ("auto")
     global VOCAB
     old = VOCAB
     VOCAB = [3001, 6, 7013, 5, 502]
