@@ -349,7 +349,9 @@ def main():
         mid = Run(preset_vocab("mid", cfg["n_sparse"]))
         mdt, _, _ = mid.timed(args.steps, args.warmup)
         extras["mid_vocab"] = dict(value=round(B * args.steps / mdt, 1), unit="examples/sec", ms_per_step=round(mdt / args.steps * 1e3, 4),
-                                   vocab="1e5 rows per field (2.6 M rows, 44 M parameters)")
+                                   vocab="1e5 rows per field (2.6 M rows, 44 M parameters)",
+                                   optimizer="deferred table update" if getattr(mid.model.optim, "_def", None) is not None
+                                   else "dense Adam sweep (TableAdam picks it below 64 M table parameters: same bits, faster there)")
         log("mid vocabulary: %.3f ms/step" % (mdt / args.steps * 1e3))
         del mid
         lazy = Run(vocab, lazy_rows=True)
