@@ -161,12 +161,13 @@ __device__ __forceinline__ void x3_fwd_pack_sym_one(const float* __restrict__ W,
     const int row = (mb * G.MT + mt) * 32 + r;
     const float* __restrict__ Wr = W + (long)(row < H ? row : 0) * ((long)m * m);
     h8 hi, lo;
+    int i = x3_sym_i(m, 8 * g), j = x3_sym_j(m, 8 * g);        // slot 8g; the next ones follow along the list's rows
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int q = 8 * g + t;
         float v = 0.f;
+        if (t > 0 && ++j > m - 1 - i) { ++i; j = i; }
         if (g < G.NS && row < H && q < x3_sym_pairs(m)) {
-            const int i = x3_sym_i(m, q), j = x3_sym_j(m, q);
             const int a = hh ? m - 1 - i : i, b = hh ? m - 1 - j : j;
             if (a == b) v = Wr[a * m + a];
             else if (!(hh && i + j == m - 1)) v = Wr[a * m + b] + Wr[b * m + a];
