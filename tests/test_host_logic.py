@@ -231,3 +231,20 @@ def test_entry_point_flags_follow_the_three_reference_scripts():
     assert y[va].sum() == 20 and y[tr].sum() == 80
     tr2, va2 = mod.split_rows(y, 0.2, 7, True)
     assert np.array_equal(tr, tr2) and np.array_equal(va, va2)
+
+
+def test_table_adam_deferred_switch(monkeypatch):
+    """TableAdam's `deferred`: True / False / "auto" (default), from the argument or XDFM_ADAM_DEFERRED = 1 / 0 / auto.
+    "auto" takes the deferred table update when the gathers' tables hold at least DEFER_MIN_NUMEL parameters and the
+    streaming sweep below (same bits either way, tests/test_gpu_host.py; DESIGN 4.3b item 4 has the crossover)."""
+    from xdfm_amd import optim
+    p = [torch.nn.Parameter(torch.zeros(4, 4))]
+    monkeypatch.delenv("XDFM_ADAM_DEFERRED", raising=False)
+    assert optim.TableAdam(p).deferred == "auto"
+    for env, want in (("0", False), ("1", True), ("auto", "auto")):
+        monkeypatch.setenv("XDFM_ADAM_DEFERRED", env)
+        assert optim.TableAdam(p).deferred == want
+        assert optim.TableAdam(p, deferred=True).deferred is True          # the argument wins over the environment
+        assert optim.TableAdam(p, deferred=False).deferred is False
+        assert optim.TableAdam(p, deferred="auto").deferred == "auto"
+    assert optim.DEFER_MIN_NUMEL == 1 << 26
