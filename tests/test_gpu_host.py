@@ -308,6 +308,26 @@ def _big_vocab_model(dev, deferred, use_graph, flush_every=5, emb_dim=D):
     return model, step, vocab
 
 
+def test_table_adam_auto_picks_the_update_by_table_size(monkeypatch):
+    """TableAdam(deferred="auto"), the default: tables of at least optim.DEFER_MIN_NUMEL parameters in total get the
+    deferred update, smaller ones the dense sweep (which is the faster way to the same bits there)."""
+    _needs_default_env('arena')
+    from oracle import xdeepfm_oracle as orc
+    from xdfm_amd import optim
+    dev = _dev()
+    seen = {}
+    for name, floor in (("deferred", 1000), ("sweep", 1 << 40)):
+        monkeypatch.setattr(optim, "DEFER_MIN_NUMEL", floor)
+        model, step, vocab = _big_vocab_model(dev, True, False)
+        model.optim.deferred = "auto"
+        for s in range(3):
+            X, y = orc.synthetic_batch(256, vocab, ND, seed=700 + s)
+            model.train_on_batch(T(X).to(dev), T(y).to(dev))
+        seen[name] = model.optim.__dict__.get("_def") is not None
+        model.optim.flush()
+    assert seen == {"deferred": True, "sweep": False}, seen
+
+
 def test_deferred_table_update_keyed_by_the_batch_rows_is_bit_identical_too(monkeypatch):
     """The step's update of the BIG tables (>= 1 M elements by default; lowered here): chunks with a gradient are enumerated
     from the batch's rows instead of by scanning the mark bytes (xdfm_adam_apply_rows); small tables, where an id occurs
