@@ -152,6 +152,55 @@ __device__ __forceinline__ void head_scores(const float (&q)[D], const float (&k
     }
 }
 
+// Head-interleaved order of a D-vector: element e of head h at e*NH + h.  A head's dot product over its HD elements is
+// a serial chain, and with the natural order [h][e] the four chains of a key row read registers that are HD apart, so
+// hipcc leaves them as scalar FMAs; interleaved, step e of all heads reads NH adjacent registers and packs into
+// v_pk_fma_f32 (two heads per instruction) -- same operations in the same order per head, so the same bits.  The forward keeps its K rows
+// in LDS in this order (forward 0.64 -> 0.595 ms at config 3; the same treatment of the backward's two passes measured
+// 4 % SLOWER -- the extra register-pair moves cost more than the packed FMAs save -- and is not in the tree).
+template <int D, int NH>
+__device__ __forceinline__ void head_interleave(const float (&x)[D], float (&y)[D]) {
+    constexpr int HD = D / NH;
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int e = 0; e < HD; ++e) y[e * NH + h] = x[h * HD + e];
+}
+// per-head dot products of two head-interleaved vectors
+typedef float attn_f2 __attribute__((ext_vector_type(2)));
+template <int D, int NH>
+__device__ __forceinline__ void head_dots_il(const float (&x)[D], const float (&y)[D], float (&a)[NH]) {
+    constexpr int HD = D / NH;
+    if constexpr (NH % 2 == 0) {
+        // two heads per v_pk_fma_f32, spelled out: the chains end in scalar code (exp), which gives hipcc's SLP
+        // vectoriser nothing to start from
+        attn_f2 acc[NH / 2];
+#pragma unroll
+        for (int hp = 0; hp < NH / 2; ++hp) acc[hp] = (attn_f2){0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < HD; ++e)
+#pragma unroll
+            for (int hp = 0; hp < NH / 2; ++hp)
+                acc[hp] = __builtin_elementwise_fma((attn_f2){x[e * NH + 2 * hp], x[e * NH + 2 * hp + 1]},
+                                                    (attn_f2){y[e * NH + 2 * hp], y[e * NH + 2 * hp + 1]}, acc[hp]);
+#pragma unroll
+        for (int hp = 0; hp < NH / 2; ++hp) { a[2 * hp] = acc[hp].x; a[2 * hp + 1] = acc[hp].y; }
+    } else {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) a[h] = 0.f;
+#pragma unroll
+        for (int e = 0; e < HD; ++e)
+#pragma unroll
+            for (int h = 0; h < NH; ++h) a[h] = fmaf(x[e * NH + h], y[e * NH + h], a[h]);
+    }
+}
+template <int D, int NH>
+__device__ __forceinline__ void head_scores_il(const float (&q)[D], const float (&k)[D], float scale, float (&sc)[NH]) {
+    head_dots_il<D, NH>(q, k, sc);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) sc[h] *= scale;
+}
+
 // One MHSA layer for the token of this thread.  The token lives in the thread's row of Xs ([S][D+1],
 // padded pitch: every thread reads its own row) and is replaced there by the layer's output
 // (post residual / LayerNorm), which is also returned in a.  Ks/Vs: [S][D] LDS; WT: this layer's
@@ -174,11 +223,15 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
         matvec_acc<D>(WT, xrow, q);
         matvec_acc<D>(WT + D * D, xrow, kk);
         matvec_acc<D>(WT + 2 * D * D, xrow, vv);
+        float ki[D];
+        head_interleave<D, NH>(kk, ki);
         if (live) {
-            store_row<D>(Ks + s * D, kk);
+            store_row<D>(Ks + s * D, ki);                // K rows head-interleaved (head_interleave above)
             store_row<D>(Vs + s * D, vv);
         }
     }
+    float qi[D];
+    head_interleave<D, NH>(q, qi);
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < NH; ++h) { mx[h] = -3.0e38f; ls[h] = 0.f; }
@@ -186,7 +239,7 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
     for (int t = 0; t < S; ++t) {                       // pass 1: row maxima (F.softmax subtracts them)
         float k[D], sc[NH];
         load_row<D>(Ks + t * D, k);
-        head_scores<D, NH>(q, k, scale, sc);
+        head_scores_il<D, NH>(qi, k, scale, sc);
 #pragma unroll
         for (int h = 0; h < NH; ++h) mx[h] = fmaxf(mx[h], sc[h]);
     }
@@ -198,7 +251,7 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
         float k[D], v[D], sc[NH];
         load_row<D>(Ks + t * D, k);
         load_row<D>(Vs + t * D, v);
-        head_scores<D, NH>(q, k, scale, sc);
+        head_scores_il<D, NH>(qi, k, scale, sc);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const float p = __expf(sc[h] - mx[h]);
