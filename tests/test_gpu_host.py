@@ -261,6 +261,10 @@ def test_attention_dropout_draws_a_new_mask_on_every_graph_replay():
       "--dnn_hidden_units", "32,16"], ["xdeepfm_pro_weights.pth", "history.json"]),
     (["--model", "xdeepfm", "--mode", "final", "--cin_layer_size", "16,8", "--dnn_hidden_units", "32,16"],
      ["xdeepfm_full_weights.pth", "history_full.json"]),
+    # xdftrain_v1.py's flow: a held-out test split, reported at the end (training_log.json: test_logloss / test_auc)
+    (["--model", "xdeepfm", "--mode", "eval", "--cin_layer_size", "16,8", "--dnn_hidden_units", "32,16",
+      "--test_size", "0.2", "--val_size", "0.2", "--stratify"],
+     ["best_model.pth", "xdeepfm_weights.pth", "training_log.json"]),
 ])
 def test_entry_point_modes_run_end_to_end(tmp_path, argv, files):
     """xdftrain_amd.py through its `--mode eval` and `--mode final` flows (xdftrain.py:302-704) for the three model
@@ -284,6 +288,9 @@ def test_entry_point_modes_run_end_to_end(tmp_path, argv, files):
         assert not any(k.startswith("val_") for k in hist) and "auc" not in hist
     else:
         assert 0.5 < hist["val_auc"][-1] <= 1.0
+    if "--test_size" in argv:
+        log = json.load(open(os.path.join(out, "training_log.json")))
+        assert 0.5 < log["test_auc"] <= 1.0 and np.isfinite(log["test_logloss"])
 
 
 def _big_vocab_model(dev, deferred, use_graph, flush_every=5, emb_dim=D):

@@ -221,7 +221,12 @@ def test_entry_point_flags_follow_the_three_reference_scripts():
             a.use_autodis, a.autodis_buckets, a.use_light_version, a.out_dir) == \
         ("pro", 5, 2048, 4096, [64, 32], False, True, True, 8, True, "./outputs_xdeepfm_pro")
     assert mod.parse_args(["--no_sfg"], model="pro").use_sfg is False
-    for shim in ("xdftrain.py", "xdftrain_attn.py", "xdftrain_pro.py"):
+    a = mod.parse_args(["--data_path", "x.txt"], model="xdeepfm", script="v1")           # xdftrain_v1.py:629-653
+    assert (a.epochs, a.test_size, a.val_size, a.patience, a.use_early_stopping, a.out_dir) == \
+        (20, 0.2, 0.2, 2, True, "./outputs_xdeepfm")
+    a = mod.parse_args(["--data_path", "x.txt"], model="xdeepfm")
+    assert (a.epochs, a.test_size, a.val_size, a.patience, a.use_early_stopping) == (3, None, 0.1, 50, False)
+    for shim in ("xdftrain.py", "xdftrain_attn.py", "xdftrain_pro.py", "xdftrain_v1.py"):
         assert os.path.exists(os.path.join(PKG, shim))
     # split: plain and stratified (class ratio kept in both parts, nothing lost, nothing shared)
     y = (np.arange(1000) % 10 == 0).astype(np.float64)

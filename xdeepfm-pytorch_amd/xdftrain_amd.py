@@ -45,10 +45,13 @@ SCRIPT_DEFAULTS = {
     "xdeepfm": dict(out_dir="./outputs_xdeepfm", epochs=3, batch_size=4096, pred_batch_size=8192),
     "attn": dict(out_dir="./outputs_xdeepfm_attn", epochs=50, batch_size=4096, pred_batch_size=8192),
     "pro": dict(out_dir="./outputs_xdeepfm_pro", epochs=20, batch_size=2048, pred_batch_size=4096),
+    # xdftrain_v1.py:629-653: the plain model with a held-out test split (--test_size), early stopping always on
+    "v1": dict(out_dir="./outputs_xdeepfm", epochs=20, batch_size=4096, pred_batch_size=8192, test_size=0.2, val_size=0.2,
+               patience=2, use_early_stopping=True),
 }
 
 
-def parse_args(argv=None, model=None):
+def parse_args(argv=None, model=None, script=None):
     p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     p.add_argument("--data_path", type=str, default=None)
     p.add_argument("--eval_path", type=str, default=None)
@@ -80,9 +83,12 @@ def parse_args(argv=None, model=None):
     p.add_argument("--epochs", type=int, default=None)
     p.add_argument("--batch_size", type=int, default=None)
     p.add_argument("--pred_batch_size", type=int, default=None)
-    p.add_argument("--val_size", type=float, default=0.1)
-    p.add_argument("--use_early_stopping", action="store_true")
-    p.add_argument("--patience", type=int, default=50)
+    p.add_argument("--val_size", type=float, default=None)
+    p.add_argument("--test_size", type=float, default=None,
+                   help="eval mode: hold this share of the rows out FIRST and report logloss / AUC on it at the end "
+                        "(xdftrain_v1.py:323-329, :402-404); the validation split is then taken from the rest")
+    p.add_argument("--use_early_stopping", action="store_true", default=None)
+    p.add_argument("--patience", type=int, default=None)
     p.add_argument("--stratify", action="store_true", help="split train/validation per label class")
     p.add_argument("--verbose", type=int, default=1, choices=[0, 1, 2])
     # xdftrain_pro.py:805-832
@@ -98,7 +104,10 @@ def parse_args(argv=None, model=None):
     p.add_argument("--autodis_buckets", type=int, default=16)
     p.add_argument("--use_light_version", action="store_true")
     args = p.parse_args(argv)
-    for k, v in SCRIPT_DEFAULTS[args.model].items():
+    for k, v in SCRIPT_DEFAULTS[script or args.model].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    for k, v in dict(val_size=0.1, patience=50, use_early_stopping=False).items():     # xdftrain.py / _attn / _pro
         if getattr(args, k) is None:
             setattr(args, k, v)
     return args
@@ -227,8 +236,8 @@ def build_model(args, cols):
                autodis_buckets=args.autodis_buckets, **common)
 
 
-def main(argv=None, model=None):
-    args = parse_args(argv, model)
+def main(argv=None, model=None, script=None):
+    args = parse_args(argv, model, script)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
@@ -253,6 +262,10 @@ def main(argv=None, model=None):
     pos = float(np.mean(table["label"] == 1))
     if rank == 0 and pos in (0.0, 1.0):
         print("[ERROR] all labels are %d: check the data file format" % int(pos))
+    test_t = None
+    if not final and args.test_size:                     # xdftrain_v1.py:323-329: test rows first, validation from the rest
+        rest, te = split_rows(table["label"], args.test_size, args.seed, args.stratify)
+        table, test_t = take(table, rest), take(table, te)
     if final:                                            # xdftrain.py:590-600: preprocessors and vocabulary from ALL rows
         train_t, val_t = table, None
     elif args.eval_path:
@@ -303,6 +316,12 @@ def main(argv=None, model=None):
             pred = model.predict({k: xva[k] for k in names}, args.pred_batch_size)
             ll, auc = M.log_loss(val_t["label"], pred), M.roc_auc_score(val_t["label"], pred)
             print("[RESULT] val logloss %.6f  val AUC %.6f  (%.1f s)" % (ll, auc, time.time() - t0))
+            test_metrics = {}
+            if test_t is not None:
+                xts = prep.transform(test_t)
+                tpred = model.predict({k: xts[k] for k in names}, args.pred_batch_size)
+                test_metrics = {"test_logloss": M.log_loss(test_t["label"], tpred), "test_auc": M.roc_auc_score(test_t["label"], tpred)}
+                print("[RESULT] test logloss %.6f  test AUC %.6f" % (test_metrics["test_logloss"], test_metrics["test_auc"]))
             if args.test_path:
                 xte = prep.transform(read_table(args.test_path, with_label=False))
                 tp = model.predict({k: xte[k] for k in names}, args.pred_batch_size)
@@ -310,7 +329,7 @@ def main(argv=None, model=None):
             history = {k: [float(v) for v in vals] for k, vals in hist.history.items()}
             torch.save(model.state_dict(), os.path.join(args.out_dir, stem + "_weights.pth"))
             json.dump(history, open(os.path.join(args.out_dir, "history.json"), "w"), indent=1)
-            json.dump({"mode": "eval", "training_time_seconds": time.time() - t0, "val_logloss": ll, "val_auc": auc,
+            json.dump({"mode": "eval", "training_time_seconds": time.time() - t0, "val_logloss": ll, "val_auc": auc, **test_metrics,
                        "data_info": {"data_path": args.data_path, "total_samples": n, "positive_ratio": pos},
                        "config": config, "history": history},
                       open(os.path.join(args.out_dir, "training_log.json"), "w"), indent=1)
