@@ -167,14 +167,6 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
  * res[b*ldres + off + r] = sum_d A[(row0 + r)][b*D + d] */
 int xdfm_cin_direct_sum(const float* A, int row0, int rows, int B, int D,
                         float* res, long ldres, int off, void* stream);
-/* the direct-connect sums of up to 8 levels in ONE launch (same sums, bit for bit): job l adds nothing new, it is the
- * argument list of one xdfm_cin_direct_sum call -- the host calls this once after the last level of a stack. */
-typedef struct {
-    const float* A;       /* [H_l][B*D] post-activation output of level l */
-    int row0, rows, off;  /* rows [row0, row0+rows) of A -> columns [off, off+rows) of res */
-} xdfm_cin_direct_sum_job;
-int xdfm_cin_direct_sum_multi(const xdfm_cin_direct_sum_job* jobs, int L, int B, int D,
-                              float* res, long ldres, void* stream);
 
 /* dOut = act'(A) * (dHid + dDirect), dbias[h] += sum_n dOut[h][n]   (autograd of :224-243).
  * A [H][N] is the saved post-activation output of the level.  Rows [hid0, hid0+hid_rows) take

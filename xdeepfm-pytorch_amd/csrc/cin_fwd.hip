@@ -341,27 +341,6 @@ __global__ __launch_bounds__(256) void cin_direct_sum_vec_kernel(const float* __
     if (n < N && (n & (D - 1)) == 0) res[(n / D) * ldres + off + r] = v;
 }
 
-// the same for the levels of a whole stack in one launch: blockIdx.y walks the rows of all jobs
-#define DS_MAXJOBS 8
-struct DirectSumJobs {
-    const float* A[DS_MAXJOBS];
-    int row0[DS_MAXJOBS], off[DS_MAXJOBS], first[DS_MAXJOBS + 1];      // first[l] = rows of the jobs before l
-};
-__global__ __launch_bounds__(256) void cin_direct_sum_multi_kernel(const DirectSumJobs J, int L, long N, int D,
-                                                                  float* __restrict__ res, long ldres) {
-    int l = 0;
-    while (l + 1 < L && (int)blockIdx.y >= J.first[l + 1]) ++l;
-    const int r = blockIdx.y - J.first[l];
-    const long n = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    float v = 0.f;
-    if (n < N) {
-        const float4 a = *reinterpret_cast<const float4*>(J.A[l] + (long)(J.row0[l] + r) * N + n);
-        v = (a.x + a.y) + (a.z + a.w);
-    }
-    for (int o = D >> 3; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    if (n < N && (n & (D - 1)) == 0) res[(n / D) * ldres + J.off[l] + r] = v;
-}
-
 template <bool POW2>
 __global__ void cin_direct_sum_kernel(const float* __restrict__ A, int row0, int rows, int B, int D,
                                       float* __restrict__ res, long ldres, int off) {
@@ -506,38 +485,6 @@ int xdfm_cin_direct_sum(const float* A, int row0, int rows, int B, int D, float*
         hipLaunchKernelGGL(cin_direct_sum_kernel<false>, dim3(ceil_div(B, 256), rows), dim3(256), 0,
                            (hipStream_t)stream, A, row0, rows, B, D, res, ldres, off);
     return xdfm_check_launch("cin_direct_sum");
-}
-
-/* all levels of a stack at once: the same sums (same code per row), one launch instead of L */
-int xdfm_cin_direct_sum_multi(const xdfm_cin_direct_sum_job* jobs, int L, int B, int D, float* res, long ldres, void* stream) {
-    XDFM_REQUIRE(jobs && res && L > 0 && L <= DS_MAXJOBS, "cin_direct_sum_multi: 1..%d jobs", DS_MAXJOBS);
-    XDFM_REQUIRE(B > 0 && D > 0, "cin_direct_sum_multi: bad shape");
-    const long N = (long)B * D;
-    bool vec = D >= 4 && D <= 64 && (D & (D - 1)) == 0 && N % 4 == 0;
-    for (int l = 0; l < L; ++l) {
-        XDFM_REQUIRE(jobs[l].A && jobs[l].rows >= 0 && jobs[l].row0 >= 0, "cin_direct_sum_multi: bad job %d", l);
-        vec = vec && (((size_t)jobs[l].A) & 15) == 0;
-    }
-    if (!vec) {
-        for (int l = 0; l < L; ++l) {
-            const int rc = xdfm_cin_direct_sum(jobs[l].A, jobs[l].row0, jobs[l].rows, B, D, res, ldres, jobs[l].off, stream);
-            if (rc) return rc;
-        }
-        return XDFM_OK;
-    }
-    DirectSumJobs J;
-    int total = 0;
-    for (int l = 0; l < DS_MAXJOBS; ++l) {
-        const xdfm_cin_direct_sum_job& j = jobs[l < L ? l : 0];
-        J.A[l] = j.A; J.row0[l] = j.row0; J.off[l] = j.off;
-        J.first[l] = total;
-        if (l < L) total += j.rows;
-    }
-    J.first[DS_MAXJOBS] = total;
-    if (total == 0) return XDFM_OK;
-    hipLaunchKernelGGL(cin_direct_sum_multi_kernel, dim3(ceil_div(N, 1024), total), dim3(256), 0, (hipStream_t)stream, J, L, N, D,
-                       res, ldres);
-    return xdfm_check_launch("cin_direct_sum_multi");
 }
 
 }  // extern "C"

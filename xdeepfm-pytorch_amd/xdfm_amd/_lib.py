@@ -34,7 +34,6 @@ SIGNATURES = {
     "xdfm_cin_pack_all": (c_int, [P, c_int, P]),
     "xdfm_cin_level_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_int, P, P]),
     "xdfm_cin_direct_sum": (c_int, [P, c_int, c_int, c_int, c_int, P, c_long, c_int, P]),
-    "xdfm_cin_direct_sum_multi": (c_int, [P, c_int, c_int, c_int, P, c_long, P]),
     "xdfm_cin_dout": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int,
                               c_int, P, P, P]),
     "xdfm_cin_dout_ws_elems": (c_size_t, [c_int, c_int, c_int]),
@@ -73,11 +72,6 @@ SIGNATURES = {
 class PackJob(ctypes.Structure):
     """xdfm_cin_pack_job of include/xdfm.h"""
     _fields_ = [("W", c_void_p), ("H", c_int), ("Hp", c_int), ("m", c_int), ("fwd_pack", c_void_p), ("bwd_pack", c_void_p)]
-
-
-class DirectSumJob(ctypes.Structure):
-    """xdfm_cin_direct_sum_job of include/xdfm.h"""
-    _fields_ = [("A", c_void_p), ("row0", c_int), ("rows", c_int), ("off", c_int)]
 
 
 class AdamTensor(ctypes.Structure):

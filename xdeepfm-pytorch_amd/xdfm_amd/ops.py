@@ -391,18 +391,11 @@ class CINStack(torch.autograd.Function):
             _lib.check(_run("cin_level_fwd", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_fwd(
                 _ptr(xp), _ptr(x0), _ptr(wf), _ptr(bias_c), H, Hp, m, N, act, _ptr(A), _stream())), "cin_level_fwd")
             _warn_if_fp32_fallback("forward", "last_fwd_kernel", H, Hp, m)
+            if pool == "sum":
+                _lib.check(lib.xdfm_cin_direct_sum(_ptr(A), dir0, drows, B, D, _ptr(result), fm, off, _stream()),
+                           "cin_direct_sum")
             outs.append(A)
             xp = A[:hid] if hid > 0 else None
-        if pool == "sum" and len(levels) <= 8:           # the direct-connect sums of all levels in one launch
-            djobs = (_lib.DirectSumJob * len(levels))()
-            for l, (H, Hp, hid, dir0, drows, off) in enumerate(levels):
-                djobs[l].A, djobs[l].row0, djobs[l].rows, djobs[l].off = outs[l].data_ptr(), dir0, drows, off
-            _lib.check(lib.xdfm_cin_direct_sum_multi(ctypes.cast(djobs, ctypes.c_void_p), len(levels), B, D, _ptr(result),
-                                                     fm, _stream()), "cin_direct_sum_multi")
-        elif pool == "sum":
-            for l, (H, Hp, hid, dir0, drows, off) in enumerate(levels):
-                _lib.check(lib.xdfm_cin_direct_sum(_ptr(outs[l]), dir0, drows, B, D, _ptr(result), fm, off, _stream()),
-                           "cin_direct_sum")
         ctx.cfg = (B, D, tuple(layer_size), split_half, act, pool, m)
         ctx.wzs = wzs                                # dX packs made up front (or None), arithmetic mode they belong to
         ctx.cin_math = _lib.get_option("cin_math")
