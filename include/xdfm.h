@@ -32,6 +32,7 @@
  * ABI 5: attention dropout in K5 (p_drop, drop_seed on xdfm_cin_attn_pool_fwd/bwd; xdfm_cin_attn_dropout_mask).
  * ABI 6: deferred (exact) Adam for the tables: xdfm_adam_tensor.last, XDFM_ADAM_DEFERRED, xdfm_adam_clock,
  * xdfm_adam_step_deferred, xdfm_adam_catchup_rows, xdfm_adam_flush.
+ * ABI 7: xdfm_cin_bwd_x_is_folded (a pure query instead of the "last_sym" probe on the product path).
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -43,7 +44,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 6
+#define XDFM_ABI_VERSION 7
 
 enum {
     XDFM_OK = 0,
@@ -201,6 +202,12 @@ int xdfm_cin_level_bwd_x(const float* dOut, const float* xp, const float* x0, co
 enum { XDFM_BWX_SET_DXP = 1, XDFM_BWX_SET_DX0 = 2 };
 int xdfm_cin_level_bwd_x_ex(const float* dOut, const float* xp, const float* x0, const float* Wz, int H, int Hp,
                             int m, long N, float* dxp, float* dx0, int flags, void* stream);
+
+/* 1 when xdfm_cin_level_bwd_x_ex called with these shapes and xp == x0 (xp_is_x0 != 0), dxp != dx0, under the current
+ * "cin_math" / "x3_sym" options runs the folded level-0 kernel, i.e. leaves the level's WHOLE gradient in dx0 (dxp zero);
+ * 0 when the caller still has to add dxp to dx0.  A pure function of its arguments and the two options: the host asks
+ * it instead of reading the process-global "last_sym" probe, which another thread's launch could have rewritten. */
+int xdfm_cin_bwd_x_is_folded(int H, int Hp, int m, int xp_is_x0);
 
 /* dW[h][i*m+j] = sum_n dOut[h][n] * x_prev[i][n] * x0[j][n]   (overwrites dW [H][Hp*m]).
  * ws: workspace of xdfm_cin_bwd_w_ws_elems floats (one partial copy of dW per n-split, summed in a

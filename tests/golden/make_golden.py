@@ -124,6 +124,10 @@ CIN_CASES = [
     ("cin_odd_last",    4,  3, 16, (8, 5),         True,  "relu"),
     ("cin_b64_m26_d16", 64, 26, 16, (32, 16, 16),  True,  "relu"),
     ("cin_b9_m22_d10",  9, 22, 10, (16, 12),       True,  "relu"),
+    # layer sizes the DEFAULT arithmetic (f16x3) has kernels for in all three directions (forward H > 32, dW H > 64, dX
+    # H > 16; level 0 of both runs the folded kernels): the goldens above all fall back to the fp32-MFMA kernels there
+    ("cin_x3_m26_d16",  8, 26, 16, (128, 96, 72),  True,  "relu"),
+    ("cin_x3_m22_d32",  6, 22, 32, (136, 96),      True,  "relu"),
 ]
 
 
@@ -213,6 +217,8 @@ MODEL_CASES = [
     ("model_attnv2_small", xDeepFMAttentionV2, [7, 5, 11, 3, 9, 4],        3,  8, (8, 6),     (16, 8),  16,
      dict(cin_num_heads=2, cin_num_attn_layers=2)),
     ("model_nodense",    xDeepFM,           [13] * 22,                     0, 16, (16, 8, 8), (16,),    24, {}),
+    # CIN levels wide enough for the f16x3 forward / dX / dW kernels (the bench's arithmetic)
+    ("model_x3_cin",     xDeepFM,           [30] * 26,                    13,  8, (96, 72),   (32, 32), 32, {}),
 ]
 
 

@@ -392,6 +392,56 @@ def test_deferred_table_update_is_bit_identical_to_the_dense_sweep(use_graph, em
     assert abs(tot_d - tot_l) <= 2e-6 * abs(tot_d), (tot_d, tot_l)
 
 
+def test_deferred_table_update_with_two_param_groups_is_bit_identical_and_stays_deferred():
+    """with a second param group (here the DNN at its own learning rate) the deferred tables of group 0 must
+    neither be flushed by that group's step nor have their clock ticked twice per step -- the bias corrections of the
+    replayed steps would be one step off.  Bits equal to `deferred=False`, and the deferral survives (one flush per
+    `flush_every` steps, not one per step)."""
+    _needs_default_env('arena')
+    from oracle import xdeepfm_oracle as orc
+    from xdfm_amd import graphstep
+    from xdfm_amd.optim import TableAdam
+    dev = _dev()
+
+    def run(deferred):
+        model, _, vocab = _big_vocab_model(dev, deferred, False)
+        dnn = [p for k, p in model.named_parameters() if k.startswith("dnn.")]
+        rest = [p for k, p in model.named_parameters() if not k.startswith("dnn.")]
+        opt = TableAdam([{"params": rest}, {"params": dnn, "lr": 2e-3}], deferred=bool(deferred), flush_every=5)
+        model.compile(opt, "binary_crossentropy", metrics=[])
+        model.optim.deferred = bool(deferred)
+        model.optim.flush_every = 5
+        model.train()
+        step = graphstep.GraphedStep(model)
+        step.disabled = True
+        model.__dict__["_graphed_step"] = step
+        flushes = [0]
+        real_flush = model.optim.flush
+
+        def counting_flush():
+            if model.optim.__dict__.get("_def") is not None and model.optim._since:
+                flushes[0] += 1
+            return real_flush()
+        model.optim.flush = counting_flush
+        for s in range(13):
+            X, y = orc.synthetic_batch(256, vocab, ND, seed=800 + s)
+            model.train_on_batch(T(X).to(dev), T(y).to(dev))
+        n_flush = flushes[0]
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        mo = [(model.optim.state[p]["exp_avg"].clone(), model.optim.state[p]["exp_avg_sq"].clone(), float(model.optim.state[p]["step"]))
+              for g in model.optim.param_groups for p in g["params"]]
+        return model, sd, mo, n_flush
+
+    m_d, sd_d, mo_d, _ = run(False)
+    m_l, sd_l, mo_l, n_flush = run(True)
+    assert len(m_l.optim.param_groups) == 2 and m_l.optim._def is not None and m_d.optim._def is None
+    assert n_flush <= 3, "13 steps at flush_every=5 flushed %d times: the second group is flushing the tables" % n_flush
+    for k in sd_d:
+        assert torch.equal(sd_d[k], sd_l[k]), k
+    for (a, b, sa), (c, d, sb) in zip(mo_d, mo_l):
+        assert torch.equal(a, c) and torch.equal(b, d) and sa == sb
+
+
 def test_deferred_table_update_fit_history_and_checkpoint_match_the_dense_sweep(tmp_path):
     """`fit` with the deferred update: the History (loss incl. the L2 term, validation metrics) equals the dense sweep's,
     a checkpoint written in the middle holds current rows, and a user-driven step (dense gradients without marks) after

@@ -71,7 +71,7 @@ def cin_math(request):
 def test_native_library_is_loaded():
     from xdfm_amd import _lib
     lib = _lib.load()
-    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 7
     assert lib.xdfm_device_count() >= 1
     with open("/proc/self/maps") as f:
         assert "libxdfm_hip.so" in f.read()
@@ -90,13 +90,23 @@ def test_cin_layer_vs_reference_golden(name, cin_math):
             c.weight.copy_(T(g["w%d" % i]))
             c.bias.copy_(T(g["b%d" % i]))
     x = T(g["x"]).to(dev).requires_grad_(True)
-    out = layer(x)
-    close(out, g["out"], msg="out")
-    (out * T(g["gout"]).to(dev)).sum().backward()
+    import warnings
+    from xdfm_amd import _lib, ops
+    ops._FALLBACK_WARNED.clear()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        out = layer(x)
+        close(out, g["out"], msg="out")
+        (out * T(g["gout"]).to(dev)).sum().backward()
     gclose(x.grad, g["dx"], "dx")
     for i, c in enumerate(layer.conv1ds):
         gclose(c.weight.grad, g["dw%d" % i], "dw%d" % i)
         gclose(c.bias.grad, g["db%d" % i], "db%d" % i)
+    if name.startswith("cin_x3_") and cin_math == 1:
+        # these goldens exist to pin the DEFAULT arithmetic's own kernels to the reference: no level may have fallen back
+        assert not [w for w in caught if "fp32-MFMA arithmetic" in str(w.message)], [str(w.message) for w in caught]
+        assert _lib.get_option("last_fwd_kernel") == _lib.get_option("last_bwx_kernel") == _lib.get_option("last_bww_kernel") == 1
+        assert _lib.get_option("last_sym") == 7          # level 0 (the last backward launches) ran the folded kernels
 
 
 @pytest.mark.parametrize("B,m,D,ls", [(130, 26, 16, (64, 32, 32)), (37, 7, 10, (40, 24)), (257, 26, 8, (128, 128)),
@@ -570,14 +580,22 @@ def test_model_vs_reference_golden(name, cin_math):
     X, y = T(g["X"]).to(dev), T(g["y"]).to(dev)
     model.compile("adam", "binary_crossentropy", metrics=["binary_crossentropy", "auc"])
     model.train()
-    y_pred = model(X[:B])
-    close(y_pred, g["y_pred"], rtol=2e-5, atol=1e-6, msg="y_pred")
-    loss = torch.nn.functional.binary_cross_entropy(y_pred.squeeze(), y[:B].squeeze(), reduction="sum")
-    reg = model.get_regularization_loss()
-    assert abs(loss.item() - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
-    assert abs(reg.item() - float(g["reg"])) <= 1e-5 * abs(float(g["reg"]))
-    model.optim.zero_grad()
-    (loss + reg).backward()
+    import warnings
+    from xdfm_amd import _lib, ops
+    ops._FALLBACK_WARNED.clear()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        y_pred = model(X[:B])
+        close(y_pred, g["y_pred"], rtol=2e-5, atol=1e-6, msg="y_pred")
+        loss = torch.nn.functional.binary_cross_entropy(y_pred.squeeze(), y[:B].squeeze(), reduction="sum")
+        reg = model.get_regularization_loss()
+        assert abs(loss.item() - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+        assert abs(reg.item() - float(g["reg"])) <= 1e-5 * abs(float(g["reg"]))
+        model.optim.zero_grad()
+        (loss + reg).backward()
+    if name.startswith("model_x3_") and cin_math == 1:
+        assert not [w for w in caught if "fp32-MFMA arithmetic" in str(w.message)], [str(w.message) for w in caught]
+        assert _lib.get_option("last_fwd_kernel") == _lib.get_option("last_bwx_kernel") == _lib.get_option("last_bww_kernel") == 1
     for k, p in model.named_parameters():
         gclose(p.grad, g["g:" + k], k)
     model.optim.zero_grad()

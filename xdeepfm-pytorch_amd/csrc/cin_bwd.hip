@@ -823,6 +823,12 @@ int xdfm_cin_level_bwd_x_ex(const float* dOut, const float* xp, const float* x0,
     }
 }
 
+int xdfm_cin_bwd_x_is_folded(int H, int Hp, int m, int xp_is_x0) {
+    // the condition of x3_level_bwd_x (cin_x3.hip) for the folded level-0 kernel, as a function of the arguments
+    return (H > 0 && H <= 256 && Hp > 0 && m > 0 && xp_is_x0 && x3_bwx_usable(H, Hp, m) && Hp == m && x3_sym_m(m) &&
+            xdfm_opt(OPT_X3_SYM) != 0) ? 1 : 0;
+}
+
 size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m, long N) {
     if (H <= 0 || Hp <= 0 || m <= 0 || N <= 0) return 0;
     const BwwGeom g = bww_geometry(H, Hp, m, N);

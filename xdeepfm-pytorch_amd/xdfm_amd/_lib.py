@@ -43,6 +43,7 @@ SIGNATURES = {
     "xdfm_cin_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "xdfm_cin_level_bwd_x": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_level_bwd_x_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P, P, c_int, P]),
+    "xdfm_cin_bwd_x_is_folded": (c_int, [c_int, c_int, c_int, c_int]),
     "xdfm_cin_bwd_w_ws_elems": (c_size_t, [c_int, c_int, c_int, c_long]),
     "xdfm_cin_level_bwd_w": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_attn_theta_elems": (c_size_t, [c_int, c_int, c_int]),
@@ -92,7 +93,7 @@ class AdamRows(ctypes.Structure):
                 ("grad", c_void_p), ("marks", c_void_p)]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _lib = None
 
 

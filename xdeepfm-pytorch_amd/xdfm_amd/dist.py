@@ -73,16 +73,30 @@ class RowParallel(object):
         return 1.0 if self.local_sizes()[self.rank] > 0 else 0.0
 
     # ---------------------------------------------------------------- collectives
+    # ONE call site per collective, whatever the backend: "nccl" (RCCL) takes device tensors as they are; "gloo" has no
+    # device transport on this stack, so a device tensor is staged through the host around the very same call
+    # (`_stage` / `_unstage`).  The world-size-2 / -4 gloo tests therefore run the production call sequence -- the same
+    # all_reduce, all_gather_into_tensor and flag exchange, on the same shapes, in the same order -- and the only code
+    # the RCCL run takes alone is the identity branch of the two staging helpers.
     def _via_host(self, t):
         return self.backend == "gloo" and t.is_cuda
 
+    def _stage(self, t):
+        return t.cpu() if self._via_host(t) else t
+
+    @staticmethod
+    def _unstage(staged, like):
+        return staged if staged.device == like.device else staged.to(like.device)
+
+    def flag_device(self):
+        """Where small control tensors of a collective live: the current GPU under RCCL, the host under gloo."""
+        return torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+
     def all_reduce_sum(self, t):
-        if self._via_host(t):
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        h = self._stage(t)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        if h is not t:
             t.copy_(h)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_gather_padded(self, t, sizes):
@@ -91,21 +105,15 @@ class RowParallel(object):
         if t.shape[0] < mx:
             pad = torch.zeros((mx - t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             t = torch.cat([t, pad], dim=0)
-        src = t.contiguous()
-        dev = src.device
-        if self._via_host(src):
-            src = src.cpu()
-        outs = [torch.empty_like(src) for _ in range(self.world)]
-        dist.all_gather(outs, src, group=self.group)
-        return [o[:s].to(dev) for o, s in zip(outs, sizes)]
+        G = self.all_gather_rows(t)
+        return [G[r * mx:r * mx + s] for r, s in enumerate(sizes)]
 
     def sum_scalar(self, t):
         v = t.detach().reshape(1).clone()
         return float(self.all_reduce_sum(v).item())
 
     def any_flag(self, flag):
-        dev = "cuda" if self.backend == "nccl" else "cpu"
-        v = torch.tensor([1.0 if flag else 0.0], device=dev)
+        v = torch.tensor([1.0 if flag else 0.0], device=self.flag_device())
         return bool(self.all_reduce_sum(v).item() > 0)
 
     def gather_rows(self, v):
@@ -135,16 +143,12 @@ class RowParallel(object):
         torch._foreach_copy_(grads, views)            # one multi-tensor launch instead of one copy per gradient
 
     def all_gather_rows(self, t):
-        """[rows, C] on every rank (same shape everywhere) -> [world * rows, C], rank-major."""
-        t = t.contiguous()
-        if self._via_host(t) or self.backend == "gloo":
-            src = t.cpu() if t.is_cuda else t
-            outs = [torch.empty_like(src) for _ in range(self.world)]
-            dist.all_gather(outs, src, group=self.group)
-            return torch.cat(outs, dim=0).to(t.device)
-        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out, t, group=self.group)
-        return out
+        """[rows, ...] on every rank (same shape everywhere) -> [world * rows, ...], rank-major: one
+        all_gather_into_tensor (a single contiguous receive buffer; no per-rank output list, no concatenation)."""
+        src = self._stage(t.contiguous())
+        out = torch.empty((self.world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src, group=self.group)
+        return self._unstage(out, t)
 
     def exchange_rows(self, X, d_emb, d_dnn, d_lin):
         """All-gather the inputs of the embedding scatter with ONE collective.

@@ -196,8 +196,12 @@ class BaseModel(nn.Module):
         dev = torch.device(self.device) if not isinstance(self.device, torch.device) else self.device
         if dev.type != "cuda":
             return
+        dp = xdist.current()
         for plan in self._plans():
-            if plan.check_ids(dev):
+            bad = plan.check_ids(dev)
+            if dp is not None:
+                bad = dp.any_flag(bad)       # every rank raises together: a lone IndexError would leave the others in a collective
+            if bad:
                 bounds = ", ".join("%d" % v for v in plan.vocab[:8]) + (" ..." if len(plan.vocab) > 8 else "")
                 raise IndexError("index out of range in self: a sparse feature id lies outside [0, vocabulary_size) "
                                  "(vocabulary sizes: %s) -- check SparseFeat(vocabulary_size=max_id + 1)" % bounds)

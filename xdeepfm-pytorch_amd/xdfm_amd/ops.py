@@ -476,7 +476,7 @@ class CINStack(torch.autograd.Function):
                     _ptr(dOc), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m, N, _ptr(dxp), _ptr(dx0), flags, _stream())),
                     "cin_level_bwd_x")
                 dx0_set = True
-            if l == 0 and not (_lib.get_option("last_sym") & 2):
+            if l == 0 and not all(lib.xdfm_cin_bwd_x_is_folded(min(hstep, H - h0), Hp, m, 1) for h0 in range(0, H, hstep)):
                 dx0 += dxp                               # x_prev of level 0 is x0 itself (the folded dX kernel has put the
                 #                                          whole gradient into dx0 already: include/xdfm.h, option x3_sym)
             dhid = dxp

@@ -76,11 +76,14 @@ class TableAdam(torch.optim.Adam):
                 hit[0] = lr
 
     def load_state_dict(self, state_dict):
+        self.flush()                 # rows that still owe replayed steps get them from the OLD moments, before those go
         out = super().load_state_dict(state_dict)
         self._invalidate()
         return out
 
     def add_param_group(self, param_group):
+        if hasattr(self, "_desc"):
+            self.flush()
         out = super().add_param_group(param_group)
         if hasattr(self, "_desc"):
             self._invalidate()
@@ -92,6 +95,7 @@ class TableAdam(torch.optim.Adam):
         self._desc = {}
         self._lr_dev = {}
         self.generation += 1
+        self._auto_numel = None      # the "auto" decision follows the param groups
         self._drop_deferred()
 
     # ------------------------------------------------------------------ deferred update of the tables
@@ -281,6 +285,7 @@ class TableAdam(torch.optim.Adam):
         self.__dict__.setdefault("flush_every", 64)
         self.__dict__["_def"] = None
         self.__dict__["_since"] = 0
+        self.__dict__["_auto_numel"] = None
         self.generation = self.__dict__.get("generation", 0) + 1
 
     def owns(self, tensors):
@@ -377,7 +382,11 @@ class TableAdam(torch.optim.Adam):
                         break
             dev = params[0].device
             d = self._def
-            if d is not None and len(deferred_now) != len(d["tensors"]):
+            if gi != 0:
+                # the deferred tables live in group 0 (`defer_ok`); a later group has nothing to do with their clock: it
+                # must neither flush them nor tick `clock[1]` a second time for the same step
+                pass
+            elif d is not None and len(deferred_now) != len(d["tensors"]):
                 # tables that were deferred arrive without marks (a user-driven loop, a row-parallel run): bring
                 # everything up to date and take this step densely; the clock only notes that a step passed
                 self.flush()
