@@ -32,7 +32,9 @@
  * ABI 5: attention dropout in K5 (p_drop, drop_seed on xdfm_cin_attn_pool_fwd/bwd; xdfm_cin_attn_dropout_mask).
  * ABI 6: deferred (exact) Adam for the tables: xdfm_adam_tensor.last, XDFM_ADAM_DEFERRED, xdfm_adam_clock,
  * xdfm_adam_step_deferred, xdfm_adam_catchup_rows, xdfm_adam_flush.
- * ABI 7: xdfm_cin_bwd_x_is_folded (a pure query instead of the "last_sym" probe on the product path).
+ * ABI 7: xdfm_cin_bwd_x_is_folded (a pure query instead of the "last_sym" probe on the product path); the deferred update's
+ * constant table holds 4 floats per step (xdfm_adam_clock.consts: 4 * cap) and its replayed steps run the short forms of
+ * csrc/adam_math.h (same bits, about half the issue slots); xdfm_adam_selftest.
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -363,8 +365,9 @@ int xdfm_adam_step_lr(const xdfm_adam_tensor* tensors, int T, double lr, const d
  * 575 M parameters) into an ALU-bound one (0.63 ms per step's worth of updates, tools/ubench/replay.hip) that touches
  * memory once per F steps.  The value of the L2 term of the replayed steps (of the weights before each replayed
  * update) is accumulated into `backlog`: summed over an epoch it equals the dense path's.
- * clock: device int[2] = {steps since the last flush, steps before it}; consts: device float[2*cap], the step size
- * lr / (1 - beta1^t) and sqrt(1 - beta2^t) of the steps since the last flush, written by the step itself. */
+ * clock: device int[2] = {steps since the last flush, steps before it}; consts: device float[4*cap] (16-byte aligned), per
+ * step since the last flush the step size lr / (1 - beta1^t), c = sqrt(1 - beta2^t), c * 2^32 and RN(1/c) * 2^-32 (0 when the
+ * step's constants fall outside the range the replay's short forms are proven for), written by the step itself. */
 typedef struct {
     int* clock;
     float* consts;
@@ -403,6 +406,14 @@ int xdfm_adam_apply_rows(const float* X, long ldx, int B, const int* cols, const
  * clock[0] = 0, every `last` byte 0). */
 int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_clock* clk, double beta1, double beta2,
                     double eps, float* backlog, void* stream);
+
+/* Test hook: compares the replay's short forms (csrc/adam_math.h) with the reference spellings ON THE DEVICE.
+ * mode 0: square root, n = 2^32 bit patterns; 1: division by a step's constant, n = steps * 2^24 numerators; 2: general
+ * division on n random operand pairs inside the guard; 3: whole replayed steps on n random chunks (zeros, denormals and
+ * huge values included: the guard's fall-back).  out: device u64[3], zeroed by the caller = {cases compared, mismatches,
+ * an encoding of one mismatching case}. */
+int xdfm_adam_selftest(int mode, unsigned long long n, unsigned long long seed, double lr, double beta1, double beta2, double eps,
+                       unsigned long long* out, void* stream);
 
 /* ------------------------------------------------------------------ SFG heads of xdeepfm_pro: tiled vocabulary CE
  * replaces: the elementwise / reduction chains around the tile GEMMs of nn.Linear(K, V) + F.cross_entropy

@@ -514,3 +514,27 @@ def test_deferred_table_update_soak_400_replayed_steps_with_the_default_period()
         assert torch.equal(sd_d[k], sd_l[k]), k
     for (a, b), (c, d) in zip(mo_d, mo_l):
         assert torch.equal(a, c) and torch.equal(b, d)
+
+
+@pytest.mark.parametrize("mode,n,what", [
+    (0, 1 << 32, "sqrt: every fp32 bit pattern (compared for 0 < x < 2^62, the replay's range)"),
+    (1, 300 << 24, "division by sqrt(1 - beta2^t): 2^24 numerators x (256 real steps + 44 random constants)"),
+    (2, 1 << 31, "general division: 2^31 random operand pairs inside the guard + its corners"),
+    (3, 1 << 22, "whole replayed steps vs adam_one on 4 M random chunks x 6 steps (zeros, denormals, huge values)"),
+], ids=["sqrt", "div_const", "div", "replay"])
+def test_fast_adam_replay_primitives_are_correctly_rounded(mode, n, what):
+    """csrc/adam_math.h: the deferred update replays missed steps with short forms of sqrt and the two divisions (packed
+    fp32, one v_rsq_f32 + one v_rcp_f32 per element, no v_div_scale / v_div_fixup).  They must give the bits of the
+    reference spelling (IEEE sqrtf and division as hipcc expands them) -- checked here on the device, the square root
+    exhaustively."""
+    import ctypes
+    from xdfm_amd import _lib
+    dev = _dev()
+    lib = _lib.load()
+    out = torch.zeros(3, dtype=torch.int64, device=dev)
+    _lib.check(lib.xdfm_adam_selftest(mode, ctypes.c_ulonglong(n), ctypes.c_ulonglong(0x5eed + mode), 1e-3, 0.9, 0.999, 1e-8,
+                                      out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), "adam_selftest")
+    torch.cuda.synchronize()
+    done, bad, case = (int(v) for v in out.tolist())
+    assert done >= n // 4, (what, done)
+    assert bad == 0, "%s: %d of %d cases differ from the reference spelling (one of them: 0x%x)" % (what, bad, done, case)

@@ -106,7 +106,7 @@ def test_cin_layer_vs_reference_golden(name, cin_math):
         # these goldens exist to pin the DEFAULT arithmetic's own kernels to the reference: no level may have fallen back
         assert not [w for w in caught if "fp32-MFMA arithmetic" in str(w.message)], [str(w.message) for w in caught]
         assert _lib.get_option("last_fwd_kernel") == _lib.get_option("last_bwx_kernel") == _lib.get_option("last_bww_kernel") == 1
-        assert _lib.get_option("last_sym") == 7          # level 0 (the last backward launches) ran the folded kernels
+        assert _lib.get_option("last_sym") & 6 == 6      # level 0 (the last dX and dW launches) ran the folded kernels
 
 
 @pytest.mark.parametrize("B,m,D,ls", [(130, 26, 16, (64, 32, 32)), (37, 7, 10, (40, 24)), (257, 26, 8, (128, 128)),

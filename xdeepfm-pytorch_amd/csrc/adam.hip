@@ -16,6 +16,7 @@
 // the pre-update weights (per-block partials summed in a fixed order by adam_l2_finish_kernel).  That removes
 // two table-sized passes per step (sum of squares; gradient initialisation) from the train step.
 #include "xdfm_internal.h"
+#include "adam_math.h"
 
 #include <algorithm>
 #include <vector>
@@ -47,27 +48,6 @@ __device__ __forceinline__ void adam_st(float4* a, const float4& x) {
     __builtin_nontemporal_store(t, reinterpret_cast<adam_v4f*>(a));
 }
 
-struct AdamCoef { float w1, b2, w2, lr, eps; };
-
-// The fusions are spelled out and the compiler's own contraction is off: left to itself it fuses differently in
-// the marked and the dense loop below, and the two must give the same bits.
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float step_size, float bc2_sqrt, const AdamCoef& c) {
-#pragma clang fp contract(off)
-    m = fmaf(c.w1, g - m, m);
-    v = fmaf(c.w2 * g, g, c.b2 * v);
-    const float denom = sqrtf(v) / bc2_sqrt + c.eps;
-    p -= step_size * m / denom;
-}
-
-// One missed step of a chunk no batch touched: the gradient is the L2 term alone.  Spelled exactly like the sweep's
-// update of an unmarked chunk (gradient = fmaf(2*l2, w, opaque zero)), so a replayed step gives the sweep's bits.
-__device__ __forceinline__ void adam_replay4(float4& p, float4& m, float4& v, float step_size, float bc2_sqrt, float g2, float zf,
-                                             const AdamCoef& c, float& sq) {
-    sq += (p.x * p.x + p.y * p.y) + (p.z * p.z + p.w * p.w);
-    float gx = fmaf(g2, p.x, zf), gy = fmaf(g2, p.y, zf), gz = fmaf(g2, p.z, zf), gw = fmaf(g2, p.w, zf);
-    adam_one(p.x, gx, m.x, v.x, step_size, bc2_sqrt, c); adam_one(p.y, gy, m.y, v.y, step_size, bc2_sqrt, c);
-    adam_one(p.z, gz, m.z, v.z, step_size, bc2_sqrt, c); adam_one(p.w, gw, m.w, v.w, step_size, bc2_sqrt, c);
-}
 #define ADAM_FIX 1099511627776.0          // 2^40: fixed-point scale of the L2 backlog (integer adds: order-independent)
 
 #define ADAM_CHUNK 40
@@ -109,6 +89,8 @@ __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
     const float l2c = *l2;
     const float g2 = 2.f * l2c;                        // d(l2 * w^2)/dw = 2 l2 w
     float sq = 0.f;
+    adam_f2 sq2 = {0.f, 0.f};                          // squares of the replayed steps (deferred tensors)
+    const bool eps_ok = c.eps >= ADAM_EPS_MIN && c.eps <= 1.f;
     const long tid = (long)lb * ADAM_THREADS + threadIdx.x;
     const long stride = (long)nb * ADAM_THREADS;
     const bool vec = ((((size_t)p) | ((size_t)m) | ((size_t)v) | ((size_t)g)) & 15) == 0;
@@ -129,7 +111,7 @@ __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
         auto process = [&](long e) {
             float4 pa = p4[e], ma = m4[e], va = v4[e], ga = g4[e];
             g4[e] = zero4; marks[e] = 0;
-            for (int s = (int)last[e] + 1; s < t; ++s) adam_replay4(pa, ma, va, consts[2 * s], consts[2 * s + 1], g2, zf, c, sq);
+            for (int s = (int)last[e] + 1; s < t; ++s) adam_replay4(pa, ma, va, adam_step_const(consts, s), g2, zf, c, sq2, eps_ok);
             sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
             ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
             adam_one(pa.x, ga.x, ma.x, va.x, step_size, bc2_sqrt, c); adam_one(pa.y, ga.y, ma.y, va.y, step_size, bc2_sqrt, c);
@@ -301,6 +283,7 @@ __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
         if (marks) { g[k] = 0.f; marks[k >> 2] = 0; }
     }
     if (l2_part) {                                     // fixed-order block reduction of the squares
+        sq += sq2.x + sq2.y;
         for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
         __shared__ float wsum[ADAM_THREADS / 64];
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
@@ -334,8 +317,16 @@ __global__ void adam_tick_kernel(int* __restrict__ clock, float* __restrict__ co
     if (t >= cap) t = cap - 1;                          // the host flushes long before (defensive)
     clock[0] = t;
     const double step = (double)(clock[1] + t);         // the value the per-parameter step counters hold at this step
-    consts[2 * t] = (float)(lr / (1.0 - pow(beta1, step)));
-    consts[2 * t + 1] = (float)sqrt(1.0 - pow(beta2, step));
+    const float ss = (float)(lr / (1.0 - pow(beta1, step)));
+    const float bc = (float)sqrt(1.0 - pow(beta2, step));
+    // the replay's short forms (adam_math.h) are proven for constants in these ranges; outside them rc2 = 0 sends the
+    // step through the reference spelling
+    const bool ok = bc >= 0.00390625f && bc <= 1.f && ss >= 9.313225746154785e-10f && ss <= 1024.f;    // 2^-8, 2^-30, 2^10
+    float* k = consts + ADAM_CONSTS_PER_STEP * t;
+    k[0] = ss;
+    k[1] = bc;
+    k[2] = bc * 4294967296.f;                           // 2^32
+    k[3] = ok ? adam_exact_rcp(bc) * 2.3283064365386963e-10f : 0.f;     // 2^-32
 }
 
 __global__ void adam_clock_reset_kernel(int* __restrict__ clock) {
@@ -362,8 +353,47 @@ struct AdamRowsDev {
     float* const* g; unsigned char* const* marks;
 };
 
-// One thread per (example, field, chunk of the row): the first thread to reach a chunk (CAS on the word that holds its
-// `last` byte) replays the steps it misses; duplicates of an id skip.  The gather runs in a later launch.
+// The chunk of thread idx -- (example, field, chunk of the row) -- and its claim: `old` >= 0 when this thread is the first
+// to reach the chunk in this launch (CAS on the word that holds its `last` byte) and has to bring it from step `old` to t;
+// duplicates of an id lose the claim and skip.
+struct AdamClaim { int f; long cc; int old; bool is_lin; };
+__device__ __forceinline__ AdamClaim adam_claim_chunk(long idx, const float* __restrict__ X, long ldx, const int* __restrict__ cols,
+                                                      const int* __restrict__ vocab, int m, int D, int QE, int QT,
+                                                      const AdamRowsDev& emb, const AdamRowsDev& lin, int t, bool need_table) {
+    AdamClaim k;
+    const int q = (int)(idx % QT);
+    const long r = idx / QT;
+    k.f = (int)(r % m);
+    const long b = r / m;
+    const int V = vocab[k.f];
+    long id = (long)X[b * ldx + cols[k.f]];             // as the gather (embed.hip): truncation, clamped
+    if (id < 0 || id >= V) id = id < 0 ? 0 : V - 1;
+    k.is_lin = q >= QE;
+    const AdamRowsDev& R = k.is_lin ? lin : emb;
+    const long w = k.is_lin ? 1 : D;
+    const long c0 = id * w / 4, c1 = (id * w + w - 1) / 4;
+    k.cc = c0 + (k.is_lin ? 0 : q);
+    const long n4 = (long)V * w / 4;                    // whole chunks; the tail elements are updated densely every step
+    k.old = -1;
+    if (k.cc <= c1 && k.cc < n4 && (!need_table || R.p[k.f] != nullptr)) {      // a null table: left to the step's mark scan (small tables)
+        unsigned char* last = R.last[k.f];
+        unsigned* word = reinterpret_cast<unsigned*>(last + (k.cc & ~3L));
+        const int sh = (int)(k.cc & 3) * 8;
+        unsigned seen = *word;          // a plain (cached) read: stale at worst, and then the CAS below returns the current word
+        while (true) {
+            const int ob = (int)((seen >> sh) & 255u);
+            if (ob >= t) break;
+            const unsigned want = (seen & ~(255u << sh)) | ((unsigned)t << sh);
+            const unsigned got = atomicCAS(word, seen, want);
+            if (got == seen) { k.old = ob; break; }
+            seen = got;
+        }
+    }
+    return k;
+}
+
+// One thread per (example, field, chunk of the row): the first thread to reach a chunk replays the steps it misses.  The
+// gather runs in a later launch.
 __global__ __launch_bounds__(ADAM_THREADS) void adam_catchup_rows_kernel(
     const float* __restrict__ X, long ldx, int B, const int* __restrict__ cols, const int* __restrict__ vocab, int m, int D,
     AdamRowsDev emb, AdamRowsDev lin, int has_lin, const int* __restrict__ clock, const float* __restrict__ consts,
@@ -372,53 +402,29 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_catchup_rows_kernel(
     const int QE = (D + 3) / 4 + ((D & 3) ? 1 : 0);     // chunks a row of D floats can straddle
     const int QT = QE + (has_lin ? 1 : 0);
     const long idx = (long)blockIdx.x * ADAM_THREADS + threadIdx.x;
-    float sqv = 0.f;
-    if (t > 0 && idx < (long)B * m * QT) {
-        const int q = (int)(idx % QT);
-        const long r = idx / QT;
-        const int f = (int)(r % m);
-        const long b = r / m;
-        const int V = vocab[f];
-        long id = (long)X[b * ldx + cols[f]];           // as the gather (embed.hip): truncation, clamped
-        if (id < 0 || id >= V) id = id < 0 ? 0 : V - 1;
-        const bool is_lin = q >= QE;
-        const AdamRowsDev& R = is_lin ? lin : emb;
-        const long w = is_lin ? 1 : D;
-        const long c0 = id * w / 4, c1 = (id * w + w - 1) / 4;
-        const long cc = c0 + (is_lin ? 0 : q);
-        const long n4 = (long)V * w / 4;                // whole chunks; the tail elements are updated densely every step
-        if (cc <= c1 && cc < n4) {
-            unsigned char* last = R.last[f];
-            unsigned* word = reinterpret_cast<unsigned*>(last + (cc & ~3L));
-            const int sh = (int)(cc & 3) * 8;
-            int old = -1;
-            unsigned seen = *word;          // a plain (cached) read: stale at worst, and then the CAS below returns the current word
-            while (true) {
-                const int ob = (int)((seen >> sh) & 255u);
-                if (ob >= t) break;
-                const unsigned want = (seen & ~(255u << sh)) | ((unsigned)t << sh);
-                const unsigned got = atomicCAS(word, seen, want);
-                if (got == seen) { old = ob; break; }
-                seen = got;
-            }
-            if (old >= 0) {
-                float4* p4 = reinterpret_cast<float4*>(R.p[f]) + cc;
-                float4* m4 = reinterpret_cast<float4*>(R.m[f]) + cc;
-                float4* v4 = reinterpret_cast<float4*>(R.v[f]) + cc;
-                float4 pa = *p4, ma = *m4, va = *v4;
-                const float l2c = R.l2[f];
-                const float g2 = 2.f * l2c;
-                float zf;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
-                const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, (float)eps};
-                float sq = 0.f;
-                for (int s = old + 1; s <= t; ++s) adam_replay4(pa, ma, va, consts[2 * s], consts[2 * s + 1], g2, zf, c, sq);
-                *p4 = pa; *m4 = ma; *v4 = va;
-                sqv = l2c * sq;
-            }
-        }
+    const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, (float)eps};
+    const bool eps_ok = c.eps >= ADAM_EPS_MIN && c.eps <= 1.f;
+    float zf;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
+    AdamClaim k;
+    k.old = -1; k.f = 0; k.cc = 0; k.is_lin = false;
+    if (t > 0 && idx < (long)B * m * QT) k = adam_claim_chunk(idx, X, ldx, cols, vocab, m, D, QE, QT, emb, lin, t, false);
+    const bool act = k.old >= 0;
+    const AdamRowsDev& R = k.is_lin ? lin : emb;
+    float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), ma = pa, va = pa;
+    float4 *p4 = nullptr, *m4 = nullptr, *v4 = nullptr;
+    float l2c = 0.f;
+    if (act) {
+        p4 = reinterpret_cast<float4*>(R.p[k.f]) + k.cc;
+        m4 = reinterpret_cast<float4*>(R.m[k.f]) + k.cc;
+        v4 = reinterpret_cast<float4*>(R.v[k.f]) + k.cc;
+        pa = *p4; ma = *m4; va = *v4;
+        l2c = R.l2[k.f];
     }
-    adam_backlog_add(sqv, backlog);
+    adam_f2 sq2 = {0.f, 0.f};
+    adam_replay_span(pa, ma, va, act, k.old, t, consts, 2.f * l2c, zf, c, sq2, eps_ok);
+    if (act) { *p4 = pa; *m4 = ma; *v4 = va; }
+    adam_backlog_add(l2c * (sq2.x + sq2.y), backlog);
 }
 
 // The step's update of the deferred tables, by the batch's rows (single process: every marked chunk belongs to a row
@@ -433,69 +439,54 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
     const int QT = QE + (has_lin ? 1 : 0);
     const long idx = (long)blockIdx.x * ADAM_THREADS + threadIdx.x;
     const long nrow = (long)B * m * QT;
-    const float ss = consts[2 * t], bc = consts[2 * t + 1];
+    const float ss = consts[ADAM_CONSTS_PER_STEP * t], bc = consts[ADAM_CONSTS_PER_STEP * t + 1];
     const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, (float)eps};
+    const bool eps_ok = c.eps >= ADAM_EPS_MIN && c.eps <= 1.f;
     float zf;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
     float sqv = 0.f;
-    if (idx < nrow) {
-        const int q = (int)(idx % QT);
-        const long r = idx / QT;
-        const int f = (int)(r % m);
-        const long b = r / m;
-        const int V = vocab[f];
-        long id = (long)X[b * ldx + cols[f]];
-        if (id < 0 || id >= V) id = id < 0 ? 0 : V - 1;
-        const bool is_lin = q >= QE;
-        const AdamRowsDev& R = is_lin ? lin : emb;
-        const long w = is_lin ? 1 : D;
-        const long c0 = id * w / 4, c1 = (id * w + w - 1) / 4;
-        const long cc = c0 + (is_lin ? 0 : q);
-        const long n4 = (long)V * w / 4;
-        if (cc <= c1 && cc < n4 && R.p[f] != nullptr) {         // a null table: left to the step's mark scan (small tables)
-            unsigned char* last = R.last[f];
-            unsigned* word = reinterpret_cast<unsigned*>(last + (cc & ~3L));
-            const int sh = (int)(cc & 3) * 8;
-            int old = -1;
-            unsigned seen = *word;          // a plain (cached) read: stale at worst, and then the CAS below returns the current word
-            while (true) {
-                const int ob = (int)((seen >> sh) & 255u);
-                if (ob >= t) break;
-                const unsigned want = (seen & ~(255u << sh)) | ((unsigned)t << sh);
-                const unsigned got = atomicCAS(word, seen, want);
-                if (got == seen) { old = ob; break; }
-                seen = got;
-            }
-            if (old >= 0) {
-                float4* p4 = reinterpret_cast<float4*>(R.p[f]) + cc;
-                float4* m4 = reinterpret_cast<float4*>(R.m[f]) + cc;
-                float4* v4 = reinterpret_cast<float4*>(R.v[f]) + cc;
-                float4* g4 = reinterpret_cast<float4*>(R.g[f]) + cc;
-                float4 pa = *p4, ma = *m4, va = *v4, ga = *g4;
-                *g4 = make_float4(zf, zf, zf, zf);
-                R.marks[f][cc] = 0;
-                const float l2c = R.l2[f];
-                const float g2 = 2.f * l2c;
-                float sq = 0.f;
-                for (int s = old + 1; s < t; ++s) adam_replay4(pa, ma, va, consts[2 * s], consts[2 * s + 1], g2, zf, c, sq);
-                sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
-                ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
-                adam_one(pa.x, ga.x, ma.x, va.x, ss, bc, c); adam_one(pa.y, ga.y, ma.y, va.y, ss, bc, c);
-                adam_one(pa.z, ga.z, ma.z, va.z, ss, bc, c); adam_one(pa.w, ga.w, ma.w, va.w, ss, bc, c);
-                *p4 = pa; *m4 = ma; *v4 = va;
-                sqv = l2c * sq;
-            }
+    AdamClaim k;
+    k.old = -1; k.f = 0; k.cc = 0; k.is_lin = false;
+    if (idx < nrow) k = adam_claim_chunk(idx, X, ldx, cols, vocab, m, D, QE, QT, emb, lin, t, true);
+    const bool act = k.old >= 0;
+    {
+        const AdamRowsDev& R = k.is_lin ? lin : emb;
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), ma = pa, va = pa, ga = pa;
+        float4 *p4 = nullptr, *m4 = nullptr, *v4 = nullptr;
+        float l2c = 0.f;
+        if (act) {
+            p4 = reinterpret_cast<float4*>(R.p[k.f]) + k.cc;
+            m4 = reinterpret_cast<float4*>(R.m[k.f]) + k.cc;
+            v4 = reinterpret_cast<float4*>(R.v[k.f]) + k.cc;
+            float4* g4 = reinterpret_cast<float4*>(R.g[k.f]) + k.cc;
+            pa = *p4; ma = *m4; va = *v4; ga = *g4;
+            *g4 = make_float4(zf, zf, zf, zf);
+            R.marks[k.f][k.cc] = 0;
+            l2c = R.l2[k.f];
         }
-    } else if (idx < nrow + 8L * m) {
+        const float g2 = 2.f * l2c;
+        adam_f2 sq2 = {0.f, 0.f};
+        adam_replay_span(pa, ma, va, act, k.old, t - 1, consts, g2, zf, c, sq2, eps_ok);     // the steps the chunk still misses
+        if (act) {                                                                           // then this step, with its gradient
+            float sq = sq2.x + sq2.y;
+            sq += (pa.x * pa.x + pa.y * pa.y) + (pa.z * pa.z + pa.w * pa.w);
+            ga.x = fmaf(g2, pa.x, ga.x); ga.y = fmaf(g2, pa.y, ga.y); ga.z = fmaf(g2, pa.z, ga.z); ga.w = fmaf(g2, pa.w, ga.w);
+            adam_one(pa.x, ga.x, ma.x, va.x, ss, bc, c); adam_one(pa.y, ga.y, ma.y, va.y, ss, bc, c);
+            adam_one(pa.z, ga.z, ma.z, va.z, ss, bc, c); adam_one(pa.w, ga.w, ma.w, va.w, ss, bc, c);
+            *p4 = pa; *m4 = ma; *v4 = va;
+            sqv = l2c * sq;
+        }
+    }
+    if (idx >= nrow && idx < nrow + 8L * m) {
         // tail elements: (table kind, field, element k < 4) -- updated every step, like the sweep does
         const long u = idx - nrow;
-        const int k = (int)(u & 3);
+        const int kk = (int)(u & 3);
         const int f = (int)((u >> 2) % m);
         const bool is_lin = (u >> 2) >= m;
         if (!is_lin || has_lin) {
             const AdamRowsDev& R = is_lin ? lin : emb;
             const long numel = (long)vocab[f] * (is_lin ? 1 : D);
-            const long e = numel / 4 * 4 + k;
+            const long e = numel / 4 * 4 + kk;
             if (e < numel && R.p[f] != nullptr) {
                 float* p = R.p[f]; float* mm = R.m[f]; float* vv = R.v[f]; float* g = R.g[f];
                 const float l2c = R.l2[f];
@@ -538,17 +529,121 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_flush_kernel(const AdamBatc
     float zf;
     asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
     const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, (float)eps};
-    float sq = 0.f;
-    for (long i = (long)lb * ADAM_THREADS + threadIdx.x; i < n4; i += (long)nb * ADAM_THREADS) {
-        const int old = last[i];
-        if (old < t) {
-            float4 pa = adam_ld<true>(p4 + i), ma = adam_ld<true>(m4 + i), va = adam_ld<true>(v4 + i);
-            for (int s = old + 1; s <= t; ++s) adam_replay4(pa, ma, va, consts[2 * s], consts[2 * s + 1], g2, zf, c, sq);
-            adam_st<true>(p4 + i, pa); adam_st<true>(m4 + i, ma); adam_st<true>(v4 + i, va);
-        }
-        if (old) last[i] = 0;
+    adam_f2 sq2 = {0.f, 0.f};
+    const bool eps_ok = c.eps >= ADAM_EPS_MIN && c.eps <= 1.f;
+    // whole-wave iterations (the replay lines the lanes up on the step number): the tail lanes are masked, not absent
+    for (long base = (long)lb * ADAM_THREADS; base < n4; base += (long)nb * ADAM_THREADS) {
+        const long i = base + threadIdx.x;
+        const bool in = i < n4;
+        const int old = in ? (int)last[i] : 0;
+        const bool act = in && old < t;
+        float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), ma = pa, va = pa;
+        if (act) { pa = adam_ld<true>(p4 + i); ma = adam_ld<true>(m4 + i); va = adam_ld<true>(v4 + i); }
+        adam_replay_span(pa, ma, va, act, old, t, consts, g2, zf, c, sq2, eps_ok);
+        if (act) { adam_st<true>(p4 + i, pa); adam_st<true>(m4 + i, ma); adam_st<true>(v4 + i, va); }
+        if (in && old) last[i] = 0;
     }
-    adam_backlog_add(l2c * sq, backlog);
+    adam_backlog_add(l2c * (sq2.x + sq2.y), backlog);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-test of the replay's short forms against the reference spellings (adam_math.h), on the device, for the tests.
+// out[0] = cases compared, out[1] = mismatches, out[2] = an encoding of one mismatching case.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long adam_mix(unsigned long long z) {       // splitmix64
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float adam_rand_float(unsigned long long h, int emin, int emax, bool sign) {     // 2^[emin, emax) x [1, 2)
+    const int e = emin + (int)((h >> 32) % (unsigned)(emax - emin));
+    const unsigned bits = ((unsigned)(e + 127) << 23) | ((unsigned)h & 0x7fffffu) | ((sign && ((h >> 60) & 1)) ? 0x80000000u : 0u);
+    return __uint_as_float(bits);
+}
+__device__ __forceinline__ AdamStepConst adam_const_for(double lr, double beta1, double beta2, double step) {
+    AdamStepConst k;
+    k.ss = (float)(lr / (1.0 - pow(beta1, step)));
+    k.bc = (float)sqrt(1.0 - pow(beta2, step));
+    k.c2 = k.bc * 4294967296.f;
+    k.rc2 = adam_exact_rcp(k.bc) * 2.3283064365386963e-10f;
+    return k;
+}
+__global__ __launch_bounds__(256) void adam_selftest_kernel(int mode, unsigned long long base, unsigned long long n,
+                                                            unsigned long long seed, double lr, double beta1, double beta2, double eps,
+                                                            unsigned long long* __restrict__ out) {
+#pragma clang fp contract(off)
+    const unsigned long long idx = base + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long bad = 0, done = 0, what = 0;
+    if (idx < n) {
+        if (mode == 0) {                    // square root: every bit pattern; compared where the replay uses it (0 < x < 2^62)
+            const float x = __uint_as_float((unsigned)idx);
+            if (x > 0.f && x < ADAM_V_MAX) {
+                const float x2 = x * 18446744073709551616.f;
+                const float fast = adam_sqrt_scaled2(adam_f2{x2, x2}).x, ref = sqrtf(x) * 4294967296.f;
+                done = 1; bad = __float_as_uint(fast) != __float_as_uint(ref); what = idx;
+            }
+        } else if (mode == 1) {             // division by the step's constant: every numerator of two binades x steps 1..
+            const unsigned mant = (unsigned)(idx & 0xffffffull);
+            const unsigned long long tt = (idx >> 24) + 1;
+            // beyond the first 256 steps: random constants in [2^-8, 1)
+            const float bc = tt <= 256 ? (float)sqrt(1.0 - pow(beta2, (double)tt)) : adam_rand_float(adam_mix(seed + tt), -8, 0, false);
+            const float S = __uint_as_float(0x3f800000u + mant);
+            const float s2 = S * 4294967296.f;
+            const float fast = adam_div_const2(adam_f2{s2, s2}, bc * 4294967296.f, adam_exact_rcp(bc) * 2.3283064365386963e-10f).y;
+            const float ref = S / bc;
+            done = 1; bad = __float_as_uint(fast) != __float_as_uint(ref); what = idx;
+        } else if (mode == 2) {             // general division inside the guard: d in [2^-40, 2^40), |n| in [2^-80, 2^40) or 0
+            const unsigned long long h0 = adam_mix(seed + 2 * idx), h1 = adam_mix(seed + 2 * idx + 1);
+            const float d = adam_rand_float(h0, -40, 40, false);
+            float nn = adam_rand_float(h1, -80, 40, true);
+            if ((h1 >> 40) % 1021 == 0) nn = 0.f;
+            if ((h1 >> 40) % 1021 == 1) nn = __uint_as_float(((h0 >> 61) & 1) ? 0x17800000u : 0x537fffffu);    // 2^-80, just under 2^40
+            const float fast = adam_div2(adam_f2{nn, nn}, adam_f2{d, d}).x, ref = nn / d;
+            done = 1; bad = __float_as_uint(fast) != __float_as_uint(ref) && !(fast == 0.f && ref == 0.f);
+            what = ((unsigned long long)__float_as_uint(nn) << 32) | __float_as_uint(d);
+        } else {                            // whole replayed steps against adam_one, states incl. zeros / denormals / huge values
+            const AdamCoef c = {(float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), 0.f, (float)eps};
+            const bool eps_ok = c.eps >= ADAM_EPS_MIN && c.eps <= 1.f;
+            float zf;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(zf));
+            float pv[4], mv[4], vv[4];
+            for (int e = 0; e < 4; ++e) {
+                const unsigned long long h = adam_mix(seed + 16 * idx + e), h2 = adam_mix(h), h3 = adam_mix(h2);
+                pv[e] = adam_rand_float(h, -30, 8, true);
+                mv[e] = adam_rand_float(h2, -60, 4, true);
+                vv[e] = adam_rand_float(h3, -100, 10, false);
+                const unsigned sel = (unsigned)((h >> 48) % 97);
+                if (sel == 0) pv[e] = 0.f;
+                if (sel == 1) { mv[e] = 0.f; vv[e] = 0.f; }
+                if (sel == 2) pv[e] = __uint_as_float(0x00000fffu);                   // denormal weight
+                if (sel == 3) { pv[e] = 3e30f; vv[e] = 1e35f; }
+                if (sel == 4) mv[e] = __uint_as_float(0x00400000u);                   // denormal first moment
+                if (sel == 5) vv[e] = __uint_as_float(0x00000001u);                   // smallest second moment
+            }
+            const float g2 = (adam_mix(seed + idx) & 7) == 0 ? 0.f : 2e-5f;
+            float4 pf = make_float4(pv[0], pv[1], pv[2], pv[3]), mf = make_float4(mv[0], mv[1], mv[2], mv[3]),
+                   vf = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            for (int st = 1; st <= 6 && !bad; ++st) {
+                const AdamStepConst k = adam_const_for(lr, beta1, beta2, (double)(st + (idx % 50) * 7));
+                float4 pr = pf, mr = mf, vr = vf;
+                adam_f2 sq2 = {0.f, 0.f};
+                adam_replay4(pf, mf, vf, k, g2, zf, c, sq2, eps_ok);
+                float* a[3] = {&pr.x, &mr.x, &vr.x};
+                for (int e = 0; e < 4; ++e) adam_one(a[0][e], fmaf(g2, a[0][e], zf), a[1][e], a[2][e], k.ss, k.bc, c);
+                const float* f[3] = {&pf.x, &mf.x, &vf.x};
+                for (int q = 0; q < 3; ++q)
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = f[q][e], y = a[q][e];
+                        if (__float_as_uint(x) != __float_as_uint(y) && !(x != x && y != y) && !(x == 0.f && y == 0.f)) bad = 1;
+                    }
+                done += 1;
+                what = idx * 8 + st;
+            }
+        }
+    }
+    if (done) atomicAdd(&out[0], done);
+    if (bad) { atomicAdd(&out[1], 1ull); atomicMax(&out[2], what); }
 }
 
 extern "C" {
@@ -696,6 +791,18 @@ int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_cloc
     }
     hipLaunchKernelGGL(adam_clock_reset_kernel, dim3(1), dim3(64), 0, st, clk->clock);
     return xdfm_check_launch("adam_flush");
+}
+
+int xdfm_adam_selftest(int mode, unsigned long long n, unsigned long long seed, double lr, double beta1, double beta2, double eps,
+                       unsigned long long* out, void* stream) {
+    XDFM_REQUIRE(out && mode >= 0 && mode <= 3 && n > 0 && n <= (1ull << 34), "adam_selftest: bad arguments");
+    const unsigned long long per = 1ull << 30;           // a launch holds fewer than 2^32 threads
+    for (unsigned long long base = 0; base < n; base += per) {
+        const unsigned long long cnt = n - base < per ? n - base : per;
+        hipLaunchKernelGGL(adam_selftest_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mode, base, n,
+                           seed, lr, beta1, beta2, eps, out);
+    }
+    return xdfm_check_launch("adam_selftest");
 }
 
 }  // extern "C"

@@ -61,6 +61,7 @@ SIGNATURES = {
     "xdfm_adam_catchup_rows": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, P, P, c_double, c_double, c_double, P, P]),
     "xdfm_adam_apply_rows": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, P, P, c_double, c_double, c_double, P, P, P]),
     "xdfm_adam_flush": (c_int, [P, c_int, P, c_double, c_double, c_double, P, P]),
+    "xdfm_adam_selftest": (c_int, [c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, c_double, c_double, c_double, c_double, P, P]),
     "xdfm_vocab_lse_update": (c_int, [P, c_long, c_int, c_int, P, P, P]),
     "xdfm_vocab_softmax_grad": (c_int, [P, c_long, c_int, c_int, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),

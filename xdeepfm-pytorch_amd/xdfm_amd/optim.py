@@ -111,7 +111,7 @@ class TableAdam(torch.optim.Adam):
         if self._def is None:
             clock = torch.zeros(2, dtype=torch.int32, device=dev)
             clock[1] = int(steps_done)
-            self._def = dict(clock=clock, consts=torch.zeros(2 * DEFER_CAP, dtype=torch.float32, device=dev),
+            self._def = dict(clock=clock, consts=torch.zeros(4 * DEFER_CAP, dtype=torch.float32, device=dev),
                              backlog=torch.zeros(1, dtype=torch.int64, device=dev), last={}, l2={}, rows={}, plans=[],
                              tensors={})
             self._def["clk"] = _lib.AdamClock(clock.data_ptr(), self._def["consts"].data_ptr(), DEFER_CAP)
