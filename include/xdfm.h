@@ -34,7 +34,8 @@
  * xdfm_adam_step_deferred, xdfm_adam_catchup_rows, xdfm_adam_flush.
  * ABI 7: xdfm_cin_bwd_x_is_folded (a pure query instead of the "last_sym" probe on the product path); the deferred update's
  * constant table holds 4 floats per step (xdfm_adam_clock.consts: 4 * cap) and its replayed steps run the short forms of
- * csrc/adam_math.h (same bits, about half the issue slots); xdfm_adam_selftest.
+ * csrc/adam_math.h (same bits, about half the issue slots); xdfm_adam_selftest; xdfm_cin_bwd_prep +
+ * xdfm_cin_level_bwd_w_prepared (dOut, its fp16 planes and the dW kernel's scales in one pass).
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -217,6 +218,23 @@ int xdfm_cin_bwd_x_is_folded(int H, int Hp, int m, int xp_is_x0);
 size_t xdfm_cin_bwd_w_ws_elems(int H, int Hp, int m, long N);
 int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
                          int H, int Hp, int m, long N, float* ws, float* dW, void* stream);
+
+/* The level's backward up to its MFMA kernels in ONE pass over dOut (f16x3 / bf16 arithmetic): xdfm_cin_dout_det that
+ * also leaves, in the dW workspace `bww_ws` (xdfm_cin_bwd_w_ws_elems floats), what xdfm_cin_level_bwd_w would otherwise
+ * produce with two more passes over dOut -- its fp16 hi / lo planes and the row scales of dOut, x_prev and x0.  The
+ * scales are per n-split of the dW kernel (a split's workgroups contract over the split's columns only), each block
+ * finds them for its own columns, and the dW kernel removes them from its accumulators before it stores the split's
+ * slab.  *prepared [host] = 1 when that happened: the caller then calls xdfm_cin_level_bwd_w_prepared with the same xp,
+ * x0, shapes, workspace and options; 0 when the shape has no f16x3 / bf16 dW kernel (H <= 64, D % 4 != 0, unaligned
+ * rows, cin_math 0): the call then was xdfm_cin_dout_det and xdfm_cin_level_bwd_w does its own passes.
+ * dout_ws: xdfm_cin_bwd_prep_ws_elems floats (dbias partials, added up in a fixed order).  dbias is added to. */
+size_t xdfm_cin_bwd_prep_ws_elems(int H, int Hp, int m, int B, int D);
+int xdfm_cin_bwd_prep(const float* A, int H, int B, int D, int act, const float* dHid, int hid0, int hid_rows,
+                      const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut,
+                      float* dbias, float* dout_ws, const float* xp, const float* x0, int Hp, int m, float* bww_ws,
+                      int* prepared, void* stream);
+int xdfm_cin_level_bwd_w_prepared(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,
+                                  float* ws, float* dW, void* stream);
 
 /* ------------------------------------------------------------------ attention pooling (K5)
  * replaces: deepctr/layers/cin_attention.py:63-97 (MultiHeadSelfAttention), :130-144

@@ -65,9 +65,12 @@ def test_workspace_size_queries():
         assert lib.xdfm_cin_fwd_pack_elems(128, 128, 7) == 1 * (128 * 4 + 4) * 64 * 4             # odd m: fp32 kernel
         assert lib.xdfm_cin_bwd_pack_elems(128, 128, 26) == 128 + (4 * 26 * 8 + 2 * 8) * 512
         assert lib.xdfm_cin_bwd_pack_elems(300, 4, 4) == 0
-        # row scales + partial row maxima (4 blocks per row) + fp16 hi/lo planes of dOut + the slabs
+        # row scales (one 256-float header per n-split: xdfm_cin_bwd_prep finds them per split) + partial row maxima of the
+        # stand-alone passes (4 blocks per row) + fp16 hi/lo planes of dOut + the slabs
         # (8-wave workgroups: 4 workgroups per n-split -> 64 splits; the fp32 kernels' 71 slabs would need less)
-        assert lib.xdfm_cin_bwd_w_ws_elems(128, 64, 26, 65536) == max(256 + 896 + 128 * 65536 + 26 * 128 * 64 * 64, 26 * 128 * 64 * 71)
+        assert lib.xdfm_cin_bwd_w_ws_elems(128, 64, 26, 65536) == max(64 * 256 + 896 + 128 * 65536 + 26 * 128 * 64 * 64, 26 * 128 * 64 * 71)
+        # dbias partials of the fused dOut pass: one per row and block of 4 splits (4096 columns) -- no more than cin_dout's own
+        assert lib.xdfm_cin_bwd_prep_ws_elems(128, 64, 26, 4096, 16) == lib.xdfm_cin_dout_ws_elems(128, 4096, 16) == 128 * 64
     finally:
         _lib.set_option("cin_math", old)
 

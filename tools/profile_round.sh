@@ -12,7 +12,7 @@ B="--steps 30 --warmup 5 --no-cpu-baseline --no-alt --no-extras"
 run_kt() {  # name, bench args
   local name=$1; shift
   timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $OUT/kt_$name -o kt -f csv -- python3 bench.py $B "$@" > $OUT/kt_$name.json 2> $OUT/kt_$name.err || { echo "kt $name failed"; return 1; }
-  python3 tools/profile_summary.py $OUT/kt_$name 39 $OUT/${R}_kernel_stats_$name.md "bench.py $B $* under rocprofv3 --kernel-trace --stats (39 profiled steps: 4 pre-capture, 5 warm-up + 30 timed replays... counted as launched); bench line of this run: $(tail -1 $OUT/kt_$name.json | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "ms/step")')"
+  python3 tools/profile_summary.py $OUT/kt_$name auto $OUT/${R}_kernel_stats_$name.md "bench.py $B $* under rocprofv3 --kernel-trace --stats (steps in the trace: 4 pre-capture + 5 warm-up + 30 timed + 2 + 10 event-bracketed eager ones); bench line of this run: $(tail -1 $OUT/kt_$name.json | python3 -c 'import json,sys; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], "ms/step")')"
 }
 run_kt card && run_kt mid --vocab-preset mid && run_kt c3 --workload criteo_c3_attn && run_kt c5 --workload avazu_c5 || exit 1
 echo "== MFMA pipe counters of the CIN kernels"

@@ -845,7 +845,7 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, in
     XDFM_REQUIRE(dOut && xp && x0 && ws && dW, "cin_level_bwd_w: null pointer");
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_w: bad shape H=%d Hp=%d m=%d", H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_bww_usable(dOut, xp, x0, H, N)) { xdfm_opt_note(OPT_LAST_BWW, xdfm_opt(OPT_CIN_MATH)); return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, st); }
+    if (x3_bww_usable(dOut, xp, x0, H, N)) { xdfm_opt_note(OPT_LAST_BWW, xdfm_opt(OPT_CIN_MATH)); return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, false, st); }
     xdfm_opt_note(OPT_LAST_BWW, 0);
     xdfm_opt_note(OPT_LAST_SYM, xdfm_opt(OPT_LAST_SYM) & ~4);
     const int phase = xdfm_opt(OPT_BWW_PHASE);            // fp32 kernels: the whole call counts as phase 2
@@ -855,6 +855,58 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0, in
         case 2: return launch_bwd_w<2>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
         default: return launch_bwd_w<4>(dOut, xp, x0, H, Hp, m, N, ws, dW, st);
     }
+}
+
+// ---- cin_dout + the dW kernel's operands in one pass (f16x3 / bf16 arithmetic) ----------------------------------
+size_t xdfm_cin_bwd_prep_ws_elems(int H, int Hp, int m, int B, int D) {
+    if (H <= 0 || Hp <= 0 || m <= 0 || B <= 0 || D <= 0) return 0;
+    const long N = (long)B * D;
+    size_t n = xdfm_cin_dout_ws_elems(H, B, D);
+    if (x3_terms() != 0 && N >= 32) {          // blocks per row of the fused pass: the larger of the two tilings a level may take
+        int blocks = x3_bwd_prep_blocks(false, H, Hp, m, N);
+        const int bs = x3_bwd_prep_blocks(true, H, Hp, m, N);
+        if (bs > blocks) blocks = bs;
+        if ((size_t)H * blocks > n) n = (size_t)H * blocks;
+    }
+    return n;
+}
+
+int xdfm_cin_bwd_prep(const float* A, int H, int B, int D, int act, const float* dHid, int hid0, int hid_rows,
+                      const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut,
+                      float* dbias, float* dout_ws, const float* xp, const float* x0, int Hp, int m, float* bww_ws,
+                      int* prepared, void* stream) {
+    XDFM_REQUIRE(prepared, "cin_bwd_prep: null pointer");
+    *prepared = 0;
+    const long N = (long)B * D;
+    const float* dh = hid_rows > 0 ? dHid : nullptr;
+    const float* dd = dir_rows > 0 ? dDir : nullptr;
+    const bool fused = dout_ws && bww_ws && xp && x0 && Hp > 0 && m > 0 && H > 0 && B > 0 && D > 0 && A && dOut &&
+                       x3_bww_usable(dOut, xp, x0, H, N) && cin_dout_vec(A, N, D, dOut, dh, dir_mode == 1 ? dd : nullptr);
+    if (!fused)
+        return xdfm_cin_dout_det(A, H, B, D, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias,
+                                 dout_ws, stream);
+    XDFM_REQUIRE(dbias, "cin_bwd_prep: null pointer");
+    XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_bwd_prep: unsupported activation %d", act);
+    XDFM_REQUIRE(hid_rows >= 0 && dir_rows >= 0 && hid0 >= 0 && dir0 >= 0 && hid0 + hid_rows <= H && dir0 + dir_rows <= H,
+                 "cin_bwd_prep: row ranges outside [0,%d)", H);
+    XDFM_REQUIRE(dir_mode == 0 || dir_mode == 1, "cin_bwd_prep: dir_mode %d", dir_mode);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = x3_bwd_prep(A, H, N, D, act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dout_ws, xp, x0,
+                         Hp, m, bww_ws, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cin_dbias_finish_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, st, dout_ws, H,
+                       x3_bwd_prep_blocks(xp == x0, H, Hp, m, N), dbias);
+    *prepared = 1;
+    return xdfm_check_launch("cin_bwd_prep");
+}
+
+int xdfm_cin_level_bwd_w_prepared(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,
+                                  float* ws, float* dW, void* stream) {
+    XDFM_REQUIRE(dOut && xp && x0 && ws && dW, "cin_level_bwd_w: null pointer");
+    XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_w: bad shape H=%d Hp=%d m=%d", H, Hp, m);
+    XDFM_REQUIRE(x3_bww_usable(dOut, xp, x0, H, N), "cin_level_bwd_w_prepared: no f16x3 / bf16 dW kernel for this call (H=%d)", H);
+    xdfm_opt_note(OPT_LAST_BWW, xdfm_opt(OPT_CIN_MATH));
+    return x3_level_bwd_w(dOut, xp, x0, H, Hp, m, N, ws, dW, true, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -7,7 +7,12 @@
 //   pass 1  x3_rowmax_kernel      partial row maxima of dOut, x_prev, x0
 //   pass 2  x3_split_dout_kernel  partial maxima -> scales (header); dOut * sD[h] -> planes [Hpad][NP/32][hi 32 | lo 32] fp16 (zero padded)
 //   pass 3  cin_bwd_w_x3_kernel   MFMA; per n-split slabs (same tiling as the fp32 kernel)
-//   pass 4  x3_bww_unpack_kernel  ordered sum of the slabs, scales removed, [h][i*m+j] layout
+//   pass 4  x3_bww_unpack_kernel  ordered sum of the slabs, [h][i*m+j] layout
+// Round 3: passes 1 and 2 are what the level's backward already does when it forms dOut -- x3_bwd_prep (below) is
+// cin_dout with two more outputs: the fp16 hi / lo planes of dOut and the scales, both per n-SPLIT of the MFMA kernel
+// (the split's workgroups contract over the split's columns only, so a scale need not hold beyond them; the MFMA kernel
+// removes its split's scales from the accumulators before it stores its slab).  The stand-alone entry point
+// (xdfm_cin_level_bwd_w on a dOut that somebody else produced) keeps passes 1 and 2 with one header for all splits.
 #include "xdfm_internal.h"
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));      // 16 bytes of MFMA operand (fp16 halves, or bf16 bit patterns)
@@ -39,13 +44,14 @@ bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, l
 }
 
 #define X3_RM_COLS 16384      // columns per block of the row-maximum pass (one block per row was 2.5x slower at N = 65536)
-struct X3BwwWs { long hdr, parts, planes, NP; int nbx; };     // element (float) counts of the workspace parts
-static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int H, int Hp, int m, long N) {
+struct X3BwwWs { long hdr, parts, planes, NP, HS; int nbx; };     // element (float) counts of the workspace parts; HS = one header
+static inline X3BwwWs x3_bww_ws(const BwwGeom& g, int H, int Hp, int m, long N, int nsplit_max) {
     X3BwwWs w;
     w.NP = round_up(N, 32);
     w.nbx = ceil_div(N, X3_RM_COLS);
-    w.hdr = round_up((long)g.Hpad + g.IPAD + m, 64);               // scales: dOut rows, x_prev rows, x0 rows
-    w.parts = round_up((long)(H + Hp + m) * w.nbx, 64);            // per-block partial row maxima
+    w.HS = round_up((long)g.Hpad + g.IPAD + m, 64);                // scales: dOut rows, x_prev rows, x0 rows
+    w.hdr = w.HS * (nsplit_max > 1 ? nsplit_max : 1);              // one header per n-split (x3_bwd_prep); the stand-alone passes fill the first
+    w.parts = round_up((long)(H + Hp + m) * w.nbx, 64);            // per-block partial row maxima (stand-alone passes)
     w.planes = (long)g.Hpad * w.NP;
     return w;
 }
@@ -199,7 +205,7 @@ __device__ __forceinline__ void x3w_split_prod2(float a0, float b0, float a1, fl
 template <int MT, int NW, int NT = 3, bool SYM = false>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
     const char* __restrict__ planes, long PB, const float* __restrict__ xp, const float* __restrict__ x0,
-    const float* __restrict__ hdr, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
+    const float* __restrict__ hdr0, long hdr_stride, int Hp, int m, long N, int IB, int JP, int TPH, long n_per_split, int Hpad,
     int IPAD, float* __restrict__ dWt, long slab_stride, int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int JT = 2;
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
         by = Lr / (int)gridDim.x;
         bx = Lr - by * (int)gridDim.x;
     }
+    const float* __restrict__ hdr = hdr0 + (long)by * hdr_stride;     // the scales of this split's columns (stride 0: one header)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -385,19 +392,36 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
         __builtin_amdgcn_s_barrier();
     }
 
+    // the split's scales leave the accumulators here (exact: powers of two, one factor at a time), so the slabs of
+    // different splits -- each with scales of its own -- add up as they are.  The row group's 32 * MT inverse dOut scales
+    // go through LDS (the staging buffers are free now): one round trip instead of one per accumulator register.
+    float* inv_sd = reinterpret_cast<float*>(smem);
+    for (int k = threadIdx.x; k < 32 * MT; k += 64 * NW)
+        inv_sd[k] = __uint_as_float(0x7f000000u - __float_as_uint(hdr[hg * 32 * MT + k]));       // 1 / 2^e, exact
+    __syncthreads();
     if (!active) return;
     const int i = iblk * 32 + r;
     float* __restrict__ dst = dWt + (long)by * slab_stride;
+    float isx[JT], isz[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        int ii, jj;
+        if constexpr (SYM) { ii = ri[jt]; jj = rj[jt]; }
+        else { ii = i < IPAD ? i : 0; jj = jp * JT + jt; jj = jj < m ? jj : 0; }
+        isx[jt] = __uint_as_float(0x7f000000u - __float_as_uint(hdr[Hpad + ii]));
+        isz[jt] = __uint_as_float(0x7f000000u - __float_as_uint(hdr[Hpad + IPAD + jj]));
+    }
     if constexpr (SYM) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const int t = jp * JT + jt;
+            for (int q = 0; q < 16; ++q) {
+                const int h = hg * 32 * MT + mt * 32 + frag_row(q, hh);
+                const float isd = inv_sd[mt * 32 + frag_row(q, hh)];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int h = hg * 32 * MT + mt * 32 + frag_row(q, hh);
-                    if (t < m / 2) dst[((long)t * Hpad + h) * 32 + r] = acc[mt][jt][q];
+                for (int jt = 0; jt < JT; ++jt) {
+                    const int t = jp * JT + jt;
+                    if (t < m / 2) dst[((long)t * Hpad + h) * 32 + r] = acc[mt][jt][q] * isd * isx[jt] * isz[jt];
                 }
             }
         return;
@@ -405,18 +429,19 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_w_x3_kernel(
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const int j = jp * JT + jt;
+        for (int q = 0; q < 16; ++q) {
+            const int h = hg * 32 * MT + mt * 32 + frag_row(q, hh);
+            const float isd = inv_sd[mt * 32 + frag_row(q, hh)];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int h = hg * 32 * MT + mt * 32 + frag_row(q, hh);
-                if (i < Hp && j < m) dst[((long)j * Hpad + h) * IPAD + i] = acc[mt][jt][q];
+            for (int jt = 0; jt < JT; ++jt) {
+                const int j = jp * JT + jt;
+                if (i < Hp && j < m) dst[((long)j * Hpad + h) * IPAD + i] = acc[mt][jt][q] * isd * isx[jt] * isz[jt];
             }
         }
 }
 
-// dW[h][i*m+j] = (sum over n-splits of dWt[split][j][h][i]) / (sD[h] * sxp[i] * sx0[j])
-__global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const float* __restrict__ hdr, int H, int Hp, int m,
+// dW[h][i*m+j] = sum over n-splits of dWt[split][j][h][i], in split order (the kernel removed each split's scales)
+__global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, int H, int Hp, int m,
                                      int Hpad, int IPAD, int nslab, long slab_stride, float* __restrict__ dW) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)m * Hpad * IPAD;
@@ -435,15 +460,13 @@ __global__ void x3_bww_unpack_kernel(const float* __restrict__ dWt, const float*
         for (int q = 0; q < 8; ++q) acc += t[q];
     }
     for (; k < nslab; ++k) acc += dWt[(long)k * slab_stride + idx];
-    const float sd = hdr[h], sx = hdr[Hpad + i], sz = hdr[Hpad + IPAD + j];
-    dW[(long)h * ((long)Hp * m) + (long)i * m + j] = acc * (1.f / sd) * (1.f / sx) * (1.f / sz);
+    dW[(long)h * ((long)Hp * m) + (long)i * m + j] = acc;
 }
 
-// folded level 0: dW[h][i*m+j] = dW[h][j*m+i] = (sum over n-splits of slab[split][t][h][r]) / (sD[h] * sx0[i] * sx0[j]),
-// (i, j) the pair of lane r in combined tile t.  One thread per slab element (coalesced reads of every split), two
-// 4-byte stores.
-__global__ void x3_bww_unpack_sym_kernel(const float* __restrict__ dWt, const float* __restrict__ hdr, int H, int m,
-                                         int Hpad, int IPAD, int nslab, long slab_stride, float* __restrict__ dW) {
+// folded level 0: dW[h][i*m+j] = dW[h][j*m+i] = sum over n-splits of slab[split][t][h][r], (i, j) the pair of lane r in
+// combined tile t.  One thread per slab element (coalesced reads of every split), two 4-byte stores.
+__global__ void x3_bww_unpack_sym_kernel(const float* __restrict__ dWt, int H, int m,
+                                         int Hpad, int nslab, long slab_stride, float* __restrict__ dW) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)(m / 2) * Hpad * 32) return;
     const int r = (int)(idx & 31);
@@ -463,7 +486,7 @@ __global__ void x3_bww_unpack_sym_kernel(const float* __restrict__ dWt, const fl
         for (int q = 0; q < 8; ++q) acc += v[q];
     }
     for (; k < nslab; ++k) acc += dWt[(long)k * slab_stride + idx];
-    const float v = acc * (1.f / hdr[h]) * (1.f / hdr[Hpad + i]) * (1.f / hdr[Hpad + IPAD + j]);
+    const float v = acc;
     float* __restrict__ row = dW + (long)h * ((long)m * m);
     row[i * m + j] = v;
     if (i != j) row[j * m + i] = v;
@@ -508,25 +531,314 @@ static BwwGeom x3_bww_geometry_sym(int H, int m, long N, int NW) {
 }
 static bool x3_bww_has_sym(int Hp, int m) { return Hp == m && x3_sym_m(m); }
 
+// n-splits of the geometry a launch will use, and the larger of the two a level with Hp == m may use (whether the level
+// IS level 0 -- x_prev == x0 -- is known at launch only): the header region of the workspace holds one header per split
+static int x3_bww_nsplit_max(int H, int Hp, int m, long N, int NW) {
+    int n = x3_bww_geometry(H, Hp, m, N, NW).nsplit;
+    if (x3_bww_has_sym(Hp, m)) {
+        const int ns = x3_bww_geometry_sym(H, m, N, NW).nsplit;
+        if (ns > n) n = ns;
+    }
+    return n;
+}
+
 size_t x3_bww_ws_elems(int H, int Hp, int m, long N) {
-    const BwwGeom g = x3_bww_geometry(H, Hp, m, N, x3_bww_waves());
-    const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);
+    const int NW = x3_bww_waves();
+    const BwwGeom g = x3_bww_geometry(H, Hp, m, N, NW);
+    const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N, x3_bww_nsplit_max(H, Hp, m, N, NW));
     size_t slabs = (size_t)g.slab * g.nsplit;
-    if (x3_bww_has_sym(Hp, m)) {            // whether the level IS level 0 (x_prev == x0) is known at launch only
-        const BwwGeom gs = x3_bww_geometry_sym(H, m, N, x3_bww_waves());
+    if (x3_bww_has_sym(Hp, m)) {
+        const BwwGeom gs = x3_bww_geometry_sym(H, m, N, NW);
         const size_t s2 = (size_t)gs.slab * gs.nsplit;
         if (s2 > slabs) slabs = s2;
     }
     return (size_t)w.hdr + (size_t)w.parts + (size_t)w.planes + slabs;
 }
 
-int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
-                   float* dW, hipStream_t st) {
+// ---------------------------------------------------------------------------------------------
+// x3_bwd_prep: cin_dout (dOut = act'(A) * (dHid + dDirect), per-block sums for dbias; cin_bwd.hip) that ALSO leaves what
+// the f16x3 / bf16 dW kernel needs -- the fp16 hi / lo planes of dOut and the row scales of dOut, x_prev and x0 -- in the
+// dW workspace, instead of two more passes over dOut (x3_rowmax_kernel + x3_split_dout_kernel re-read 2 x 67 MB per
+// level at config 2).  The scales are per n-SPLIT of the MFMA kernel: a block owns one row and KS whole splits
+// (<= 4096 columns, values kept in registers between the maximum and the split), the maxima of its splits form in LDS
+// with integer atomics (order-independent), and nothing crosses a block.
+// grid.y walks the header slots: [0, Hpad) dOut rows (rows >= H are zero planes with scale 1), [Hpad, Hpad + IPAD)
+// x_prev rows, then the m rows of x0 (maxima only).
+// ---------------------------------------------------------------------------------------------
+#define X3_PREP_COLS 4096
+// exact n / d for 0 <= n < 2^31 with a multiplication: M = ceil(2^(31 + s) / d), s = ceil(log2 d) (64-bit integer
+// division costs ~100 VALU instructions on this hardware, and the kernel below would do 12 of them per 32 columns)
+struct X3Magic { unsigned M; int s; };
+static X3Magic x3_magic(long d) {
+    X3Magic k;
+    k.s = 0;
+    while ((1L << k.s) < d) ++k.s;
+    k.M = (unsigned)((((unsigned long long)1 << (31 + k.s)) + (unsigned long long)d - 1) / (unsigned long long)d);
+    if (d == 1) k.M = 0x80000000u;
+    return k;
+}
+__device__ __forceinline__ int x3_div(unsigned n, X3Magic k) { return (int)(((unsigned long long)n * k.M) >> (31 + k.s)); }
+
+template <int NT>
+__global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
+    const float* __restrict__ A, int H, long N, X3Magic divD, int act,
+    const float* __restrict__ dHid, int hid0, int hid_rows,
+    const float* __restrict__ dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+    float* __restrict__ dOut, float* __restrict__ slots,
+    const float* __restrict__ xp, const float* __restrict__ x0, int Hp, int m, int Hpad, int IPAD,
+    int n_per_split, X3Magic divS, int KS, int nsplit, float* __restrict__ hdr2, long HS, char* __restrict__ planes, long NP) {
+    __shared__ unsigned seg_max[X3_PREP_COLS / 32 + 1];
+    __shared__ float wsum[4];
+    const int y = blockIdx.y;
+    const int s0 = blockIdx.x * KS;                                   // first split of this block
+    const int ns = s0 + KS <= nsplit ? KS : nsplit - s0;              // its splits
+    const long c0 = (long)s0 * n_per_split;
+    long c1l = c0 + (long)ns * n_per_split;                           // plane columns [c0, c1), multiples of 32
+    c1l = c1l < NP ? c1l : NP;
+    const int span = (int)(c1l - c0);                                 // columns of this block (offsets below are relative to c0)
+    const int nreal = (int)((N < c1l ? N : c1l) - c0);                // ... of which these exist (N % 4 == 0); <= 0: none
+    for (int k = threadIdx.x; k < ns; k += 256) seg_max[k] = 0u;
+    __syncthreads();
+    const bool reg = span <= X3_PREP_COLS;                            // values stay in registers between the two phases
+    const bool is_d = y < Hpad, is_xp = !is_d && y < Hpad + IPAD;
+    const int row = is_d ? y : (is_xp ? y - Hpad : y - Hpad - IPAD);
+    const bool real = is_d ? row < H : (is_xp ? row < Hp : true);
+    const float* __restrict__ src = (is_d ? A + (long)(real ? row : 0) * N : (is_xp ? xp + (long)(real ? row : 0) * N : x0 + (long)row * N)) + c0;
+    const bool has_hid = is_d && real && dHid && row >= hid0 && row < hid0 + hid_rows;
+    const bool has_dir = is_d && real && dDir && row >= dir0 && row < dir0 + dir_rows;
+    const float* __restrict__ hrow = has_hid ? dHid + (long)(row - hid0) * N + c0 : nullptr;
+    const float* __restrict__ drow = (has_dir && dir_mode == 1) ? dDir + (long)(dir_off + row - dir0) * N + c0 : nullptr;
+    const float* __restrict__ dres = (has_dir && dir_mode == 0) ? dDir + dir_off + (row - dir0) : nullptr;
+    float* __restrict__ orow = dOut + (long)(is_d && real ? row : 0) * N + c0;
+    // the values of 4 columns at offset o (o % 4 == 0, o < nreal): dOut for a dOut row, the operand itself for x_prev / x0
+    auto value = [&](int o) -> float4 {
+        const float4 av = *reinterpret_cast<const float4*>(src + o);
+        if (!is_d) return av;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hrow) g = *reinterpret_cast<const float4*>(hrow + o);
+        if (drow) { const float4 dv = *reinterpret_cast<const float4*>(drow + o); g.x += dv.x; g.y += dv.y; g.z += dv.z; g.w += dv.w; }
+        if (dres) { const float rr = dres[(long)x3_div((unsigned)(c0 + o), divD) * lddir]; g.x += rr; g.y += rr; g.z += rr; g.w += rr; }   // one example
+        if (act == XDFM_ACT_RELU) {
+            if (!(av.x > 0.f)) g.x = 0.f;
+            if (!(av.y > 0.f)) g.y = 0.f;
+            if (!(av.z > 0.f)) g.z = 0.f;
+            if (!(av.w > 0.f)) g.w = 0.f;
+        }
+        return g;
+    };
+    // a thread owns 8 consecutive columns per iteration (two float4): 16-byte stores into the hi and the lo half of a plane block
+    float4 gv[2][2];
+    float part = 0.f;
+    const int iters = (span + 2047) / 2048;
+    auto relu_mask = [&](float4& g, const float4& av) {
+        if (act == XDFM_ACT_RELU) {
+            if (!(av.x > 0.f)) g.x = 0.f;
+            if (!(av.y > 0.f)) g.y = 0.f;
+            if (!(av.z > 0.f)) g.z = 0.f;
+            if (!(av.w > 0.f)) g.w = 0.f;
+        }
+    };
+    auto account = [&](int o, const float4& g0, const float4& g1) {       // dOut store, dbias share, split maximum of 8 columns
+        if (is_d) {
+            *reinterpret_cast<float4*>(orow + o) = g0;
+            if (o + 4 < nreal) *reinterpret_cast<float4*>(orow + o + 4) = g1;
+            part += ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w));
+        }
+        if (NT == 3) {
+            const float mx = fmaxf(fmaxf(fmaxf(fabsf(g0.x), fabsf(g0.y)), fmaxf(fabsf(g0.z), fabsf(g0.w))),
+                                   fmaxf(fmaxf(fabsf(g1.x), fabsf(g1.y)), fmaxf(fabsf(g1.z), fabsf(g1.w))));
+            // 8 | 32 | n_per_split: the 8 columns lie in one split.  Non-negative floats order like their bits.
+            atomicMax(&seg_max[x3_div((unsigned)o, divS)], __float_as_uint(mx));
+        }
+    };
+    // `account` when the whole wave is inside the block's columns: the wave's 512 columns usually lie in ONE split, and
+    // then one lane speaks for all 64 (64 LDS atomics on one address take 64 turns)
+    auto account_wave = [&](int o, const float4& g0, const float4& g1) {
+        if (is_d) {
+            *reinterpret_cast<float4*>(orow + o) = g0;
+            *reinterpret_cast<float4*>(orow + o + 4) = g1;
+            part += ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w));
+        }
+        if (NT == 3) {
+            float mx = fmaxf(fmaxf(fmaxf(fabsf(g0.x), fabsf(g0.y)), fmaxf(fabsf(g0.z), fabsf(g0.w))),
+                             fmaxf(fmaxf(fabsf(g1.x), fabsf(g1.y)), fmaxf(fabsf(g1.z), fabsf(g1.w))));
+            const int seg = x3_div((unsigned)o, divS);
+            const int seg_first = __builtin_amdgcn_readfirstlane(seg);
+            if (__builtin_amdgcn_ballot_w64(seg != seg_first) == 0) {
+                for (int k = 32; k > 0; k >>= 1) mx = fmaxf(mx, __shfl_xor(mx, k));
+                if ((threadIdx.x & 63) == 0) atomicMax(&seg_max[seg], __float_as_uint(mx));
+            } else {
+                atomicMax(&seg_max[seg], __float_as_uint(mx));
+            }
+        }
+    };
+    if (real && (NT == 3 || is_d)) {
+        if (reg) {
+            // <= 2 iterations: EVERY load of the block's columns goes out before the first one is used -- unconditional
+            // loads from clamped offsets, masked afterwards (behind per-load conditions hipcc waits for each load in turn:
+            // one load in flight per thread, 2.7 TB/s); the operand choices (dHid / dDir rows) are block-uniform
+            int o[2], oc[2][2];
+            float msk[2][2];
+            float4 av[2][2], g[2][2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                o[it] = (it * 256 + (int)threadIdx.x) * 8;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bool ok = it < iters && o[it] + 4 * q < nreal;
+                    oc[it][q] = ok ? o[it] + 4 * q : 0;
+                    msk[it][q] = ok ? 1.f : 0.f;
+                    av[it][q] = *reinterpret_cast<const float4*>(src + oc[it][q]);
+                    g[it][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            if (hrow) {
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) g[it][q] = *reinterpret_cast<const float4*>(hrow + oc[it][q]);
+            }
+            if (drow) {
+                float4 dv[2][2];
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) dv[it][q] = *reinterpret_cast<const float4*>(drow + oc[it][q]);
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { g[it][q].x += dv[it][q].x; g[it][q].y += dv[it][q].y; g[it][q].z += dv[it][q].z; g[it][q].w += dv[it][q].w; }
+            }
+            if (dres) {
+                float rr[2][2];
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) rr[it][q] = dres[(long)x3_div((unsigned)(c0 + oc[it][q]), divD) * lddir];     // 4 columns: one example
+#pragma unroll
+                for (int it = 0; it < 2; ++it)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) { g[it][q].x += rr[it][q]; g[it][q].y += rr[it][q]; g[it][q].z += rr[it][q]; g[it][q].w += rr[it][q]; }
+            }
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (is_d) relu_mask(g[it][q], av[it][q]);
+                    else g[it][q] = av[it][q];
+                    g[it][q].x *= msk[it][q]; g[it][q].y *= msk[it][q]; g[it][q].z *= msk[it][q]; g[it][q].w *= msk[it][q];
+                    gv[it][q] = g[it][q];
+                }
+                const int wave_o = (it * 256 + ((int)threadIdx.x & ~63)) * 8;          // first column of this wave in this iteration
+                if (it < iters && wave_o + 512 <= nreal) account_wave(o[it], g[it][0], g[it][1]);
+                else if (it < iters && o[it] < nreal) account(o[it], g[it][0], g[it][1]);
+            }
+        } else {
+            for (int it = 0; it < iters; ++it) {
+                const int o = (it * 256 + (int)threadIdx.x) * 8;
+                float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+                if (o < nreal) g0 = value(o);
+                if (o + 4 < nreal) g1 = value(o + 4);
+                if (o < nreal) account(o, g0, g1);
+            }
+        }
+    }
+    if (is_d && real) {                                               // dbias: this block's share, summed in block order later
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = part;
+    }
+    // LDS only crosses this barrier (maxima, wave sums): the dOut stores above stay in flight behind it (__syncthreads
+    // would wait for every one of them to be acknowledged before the first plane store goes out)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (is_d && real && threadIdx.x == 0) slots[(long)row * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    // the splits' scales: dOut rows < 2^15, x_prev / x0 rows < 2^7 (|Z| < 2^14); 1 for padding rows and for bf16
+    const int target = is_d ? 15 : 7;
+    for (int k = threadIdx.x; k < ns; k += 256) {
+        const float sc = (NT == 3 && real) ? x3w_pow2_scale(__uint_as_float(seg_max[k]), target) : 1.f;
+        hdr2[(long)(s0 + k) * HS + y] = sc;
+    }
+    if (!is_d) return;
+    // planes of this row and these columns: [hi 32 halves | lo 32 halves] per 32 columns, zero beyond N and for rows >= H
+    char* __restrict__ prow = planes + ((long)y * NP + c0) * 4;
+    for (int it = 0; it < iters; ++it) {
+        const int o = (it * 256 + (int)threadIdx.x) * 8;
+        if (o >= span) break;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
+        if (real) {
+            if (reg) { g0 = gv[it & 1][0]; g1 = gv[it & 1][1]; }
+            else { if (o < nreal) g0 = value(o); if (o + 4 < nreal) g1 = value(o + 4); }
+        }
+        float sc = 1.f;
+        if (NT == 3 && real) sc = x3w_pow2_scale(__uint_as_float(seg_max[x3_div((unsigned)o, divS)]), 15);
+        const float v[8] = {g0.x * sc, g0.y * sc, g0.z * sc, g0.w * sc, g1.x * sc, g1.y * sc, g1.z * sc, g1.w * sc};
+        h8 hi, lo;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (NT == 3) {
+                const _Float16 a = (_Float16)v[t];
+                hi[t] = a;
+                lo[t] = (_Float16)(v[t] - (float)a);
+            } else {
+                hi[t] = __builtin_bit_cast(_Float16, (__bf16)v[t]);
+                lo[t] = (_Float16)0.f;
+            }
+        }
+        char* blk = prow + (long)(o & ~31) * 4 + (o & 31) * 2;
+        *reinterpret_cast<h8*>(blk) = hi;
+        if (NT == 3) *reinterpret_cast<h8*>(blk + 64) = lo;
+    }
+}
+
+// geometry of the dW launch that will follow for these arguments (x3_level_bwd_w takes the same decisions)
+static BwwGeom x3_bww_launch_geometry(const float* xp, const float* x0, int H, int Hp, int m, long N, int NW, bool* sym) {
+    *sym = xp == x0 && x3_bww_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0;
+    return *sym ? x3_bww_geometry_sym(H, m, N, NW) : x3_bww_geometry(H, Hp, m, N, NW);
+}
+
+// cin_dout + the dW kernel's operands (see x3_bwd_prep_kernel).  slots: H * x3_bwd_prep_slots() floats of dbias partials
+// (the caller adds them up in block order).  ws: the dW workspace.
+int x3_bwd_prep_blocks(bool xp_is_x0, int H, int Hp, int m, long N) {
+    const bool sym = xp_is_x0 && x3_bww_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0;
+    const BwwGeom g = sym ? x3_bww_geometry_sym(H, m, N, x3_bww_waves()) : x3_bww_geometry(H, Hp, m, N, x3_bww_waves());
+    const int KS = g.n_per_split >= X3_PREP_COLS ? 1 : (int)(X3_PREP_COLS / g.n_per_split);
+    return ceil_div(g.nsplit, KS);
+}
+
+int x3_bwd_prep(const float* A, int H, long N, int D, int act, const float* dHid, int hid0, int hid_rows, const float* dDir,
+                int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut, float* slots, const float* xp,
+                const float* x0, int Hp, int m, float* ws, hipStream_t st) {
     const int NW = x3_bww_waves();
-    BwwGeom g = x3_bww_geometry(H, Hp, m, N, NW);
-    const X3BwwWs w = x3_bww_ws(g, H, Hp, m, N);          // header, partial maxima, planes: the same in both tilings
-    const bool sym = xp == x0 && x3_bww_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0;
-    if (sym) g = x3_bww_geometry_sym(H, m, N, NW);
+    bool sym;
+    const BwwGeom g = x3_bww_launch_geometry(xp, x0, H, Hp, m, N, NW, &sym);
+    const X3BwwWs w = x3_bww_ws(x3_bww_geometry(H, Hp, m, N, NW), H, Hp, m, N, x3_bww_nsplit_max(H, Hp, m, N, NW));
+    if ((((size_t)ws) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_bwd_prep: workspace must be 16-byte aligned");
+    float* hdr2 = ws;
+    char* planes = reinterpret_cast<char*>(ws + w.hdr + w.parts);
+    const int KS = g.n_per_split >= X3_PREP_COLS ? 1 : (int)(X3_PREP_COLS / g.n_per_split);
+    const dim3 grid(ceil_div(g.nsplit, KS), g.Hpad + g.IPAD + m);
+    XDFM_REQUIRE(grid.y <= 65535, "cin_bwd_prep: %d header rows", (int)grid.y);
+    XDFM_REQUIRE(N < (1L << 31) && g.n_per_split < (1L << 30), "cin_bwd_prep: N = %ld columns", N);
+    const X3Magic divD = x3_magic(D), divS = x3_magic(g.n_per_split);
+    if (x3_terms() == 3)
+        hipLaunchKernelGGL(x3_bwd_prep_kernel<3>, grid, dim3(256), 0, st, A, H, N, divD, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir,
+                           dir_off, dir0, dir_rows, dOut, slots, xp, x0, Hp, m, g.Hpad, g.IPAD, (int)g.n_per_split, divS, KS, g.nsplit, hdr2,
+                           w.HS, planes, w.NP);
+    else
+        hipLaunchKernelGGL(x3_bwd_prep_kernel<1>, grid, dim3(256), 0, st, A, H, N, divD, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir,
+                           dir_off, dir0, dir_rows, dOut, slots, xp, x0, Hp, m, g.Hpad, g.IPAD, (int)g.n_per_split, divS, KS, g.nsplit, hdr2,
+                           w.HS, planes, w.NP);
+    return xdfm_check_launch("cin_bwd_prep (f16x3 / bf16)");
+}
+
+// prepared: x3_bwd_prep has filled the planes and the per-split headers of `ws` for these very arguments
+int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
+                   float* dW, bool prepared, hipStream_t st) {
+    const int NW = x3_bww_waves();
+    bool sym;
+    const BwwGeom g = x3_bww_launch_geometry(xp, x0, H, Hp, m, N, NW, &sym);
+    // header(s), partial maxima, planes: the same in both tilings
+    const X3BwwWs w = x3_bww_ws(x3_bww_geometry(H, Hp, m, N, NW), H, Hp, m, N, x3_bww_nsplit_max(H, Hp, m, N, NW));
     xdfm_opt_note(OPT_LAST_SYM, (xdfm_opt(OPT_LAST_SYM) & ~4) | (sym ? 4 : 0));
     if ((((size_t)ws) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_w: workspace must be 16-byte aligned");
     float* hdr = ws;
@@ -538,7 +850,7 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     const int phase = xdfm_opt(OPT_BWW_PHASE);
     int rc = XDFM_OK;
     const int nt = x3_terms();
-    if (phase == 0 || phase == 1) {
+    if (!prepared && (phase == 0 || phase == 1)) {
     if (nt == 1) {                      // bf16: no row scales, no maxima pass
     } else if (w.nbx == 1) {            // one block covers a row: the maxima pass writes the scales itself
         hipLaunchKernelGGL(x3_rowmax_kernel, dim3(1, g.Hpad + g.IPAD + m), dim3(256), 0, st, dOut, xp, x0, H, Hp, N, parts,
@@ -558,12 +870,13 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     if (phase == 0 || phase == 2) {
     const size_t lds = (size_t)2 * (32 * 4 + NW * (32 + 8)) * 128;
     const int xcd = xdfm_opt(OPT_BWW_XCD) != 0 ? 1 : 0;
+    const long hstride = prepared ? w.HS : 0;          // per-split headers, or the one header of the stand-alone passes
 #define BWW_LAUNCH(NWV, NTV) \
     hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, NWV, NTV>), dim3(g.gx, g.nsplit), dim3(64 * NWV), lds, st, planes, w.NP * 4, xp, \
-                       x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab, xcd)
+                       x0, hdr, hstride, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab, xcd)
 #define BWW_LAUNCH_SYM(NWV, NTV) \
     hipLaunchKernelGGL((cin_bwd_w_x3_kernel<4, NWV, NTV, true>), dim3(g.gx, g.nsplit), dim3(64 * NWV), lds, st, planes, w.NP * 4, xp, \
-                       x0, hdr, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab, xcd)
+                       x0, hdr, hstride, Hp, m, N, g.IB, g.JP, g.TPH, g.n_per_split, g.Hpad, g.IPAD, slabs, g.slab, xcd)
     if (sym) {
         if (NW == 8) { if (nt == 3) BWW_LAUNCH_SYM(8, 3); else BWW_LAUNCH_SYM(8, 1); }
         else { if (nt == 3) BWW_LAUNCH_SYM(4, 3); else BWW_LAUNCH_SYM(4, 1); }
@@ -575,11 +888,11 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
     if (rc) return rc;
     }
     if ((phase == 0 || phase == 3) && sym) {
-    hipLaunchKernelGGL(x3_bww_unpack_sym_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, slabs, hdr, H, m,
-                       g.Hpad, g.IPAD, g.nsplit, g.slab, dW);
+    hipLaunchKernelGGL(x3_bww_unpack_sym_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, slabs, H, m,
+                       g.Hpad, g.nsplit, g.slab, dW);
     rc = xdfm_check_launch("cin_level_bwd_w unpack (folded level 0)");
     } else if (phase == 0 || phase == 3) {
-    hipLaunchKernelGGL(x3_bww_unpack_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, slabs, hdr, H, Hp, m, g.Hpad,
+    hipLaunchKernelGGL(x3_bww_unpack_kernel, dim3(ceil_div(g.slab, 256)), dim3(256), 0, st, slabs, H, Hp, m, g.Hpad,
                        g.IPAD, g.nsplit, g.slab, dW);
     rc = xdfm_check_launch("cin_level_bwd_w unpack (f16x3)");
     }

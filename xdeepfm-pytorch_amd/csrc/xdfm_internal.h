@@ -192,7 +192,12 @@ static inline BwwGeom bww_geometry(int H, int Hp, int m, long N) {
 bool x3_bww_usable(const float* dOut, const float* xp, const float* x0, int H, long N);
 size_t x3_bww_ws_elems(int H, int Hp, int m, long N);
 int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N, float* ws,
-                   float* dW, hipStream_t st);
+                   float* dW, bool prepared, hipStream_t st);
+// cin_dout that also leaves the dW kernel's operands (planes, per-split scales) in the dW workspace (cin_x3_bww.hip)
+int x3_bwd_prep_blocks(bool xp_is_x0, int H, int Hp, int m, long N);      // dbias partials per row
+int x3_bwd_prep(const float* A, int H, long N, int D, int act, const float* dHid, int hid0, int hid_rows, const float* dDir,
+                int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut, float* slots, const float* xp,
+                const float* x0, int Hp, int m, float* ws, hipStream_t st);
 
 bool x3_pack_all_usable(int H, int Hp, int m);
 int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st);

@@ -39,6 +39,10 @@ SIGNATURES = {
     "xdfm_cin_dout_ws_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_dout_det": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int,
                                   c_int, P, P, P, P]),
+    "xdfm_cin_bwd_prep_ws_elems": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "xdfm_cin_bwd_prep": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int, c_int, P, P, P,
+                                  P, P, c_int, c_int, P, P, P]),
+    "xdfm_cin_level_bwd_w_prepared": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_bwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
     "xdfm_cin_level_bwd_x": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, P, P, P]),

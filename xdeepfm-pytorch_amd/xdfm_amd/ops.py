@@ -429,16 +429,24 @@ class CINStack(torch.autograd.Function):
             dOut = torch.empty((H, N), dtype=torch.float32, device=dev)
             dbias = dbias_all[dbias_off[l]:dbias_off[l] + H]
             has_hid = dhid is not None and hid > 0
-            dws = torch.empty(lib.xdfm_cin_dout_ws_elems(H, B, D), dtype=torch.float32, device=dev)   # fixed-order dbias
-            _lib.check(lib.xdfm_cin_dout_det(_ptr(A), H, B, D, act, _ptr(dhid) if has_hid else None, 0,
-                                             hid if has_hid else 0, _ptr(g), 0 if pool == "sum" else 1,
-                                             fm if pool == "sum" else N, off, dir0, drows, _ptr(dOut), _ptr(dbias),
-                                             _ptr(dws), _stream()), "cin_dout")
-            if ctx.needs_input_grad[7 + 2 * l]:
-                ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m, N), dtype=torch.float32, device=dev)
+            need_dw = ctx.needs_input_grad[7 + 2 * l]
+            # dOut (+ dbias), and in the same pass -- when the f16x3 / bf16 dW kernel will run for this level -- the fp16
+            # planes of dOut and the dW kernel's scales, straight into the dW workspace (xdfm_cin_bwd_prep)
+            dws = torch.empty(lib.xdfm_cin_bwd_prep_ws_elems(H, Hp, m, B, D), dtype=torch.float32, device=dev)   # fixed-order dbias
+            ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m, N), dtype=torch.float32, device=dev) if need_dw else None
+            prepared = ctypes.c_int(0)
+            _lib.check(_run("cin_dout", 0.0, lambda: lib.xdfm_cin_bwd_prep(
+                _ptr(A), H, B, D, act, _ptr(dhid) if has_hid else None, 0, hid if has_hid else 0, _ptr(g),
+                0 if pool == "sum" else 1, fm if pool == "sum" else N, off, dir0, drows, _ptr(dOut), _ptr(dbias), _ptr(dws),
+                _ptr(xp), _ptr(x0), Hp, m, _ptr(ws), ctypes.byref(prepared), _stream())), "cin_dout")
+            if need_dw:
                 dW = torch.empty((H, Hp * m), dtype=torch.float32, device=dev)
-                call = lambda: lib.xdfm_cin_level_bwd_w(_ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW),
-                                                        _stream())
+                if prepared.value:
+                    call = lambda: lib.xdfm_cin_level_bwd_w_prepared(_ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW),
+                                                                      _stream())
+                else:
+                    call = lambda: lib.xdfm_cin_level_bwd_w(_ptr(dOut), _ptr(xp), _ptr(x0), H, Hp, m, N, _ptr(ws), _ptr(dW),
+                                                             _stream())
                 if PROFILE is not None and _lib.get_option("cin_math") in (1, 2):
                     # per-kernel timing: run the call's three phases separately, events around the MFMA kernel only
                     # (a shape without an f16x3 dW kernel ignores the knob: its whole call then runs once, in phase 2)
