@@ -44,6 +44,10 @@ CIN_MATH = {0: ("f32mfma", FP32_MFMA_PEAK_TFLOPS, "v_mfma_f32_32x32x2_f32 on fp3
                 "operands rounded to bf16, 1 x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate (BASELINE config 5's "
                 "arithmetic; tolerance 2e-2 / 4e-2 of a tensor's largest magnitude, tests/test_gpu_parity.py)")}
 HBM_PEAK_GBS = 8000.0
+# K5 (attention block of config 3): scores and P.V as fp32 MFMAs (v_mfma_f32_32x32x2_f32) -- priced against the fp32 matrix peak
+ATTN_PEAK_TFLOPS = FP32_MFMA_PEAK_TFLOPS
+ATTN_NOTE = ("FLOPs of the reference's attention block per launch (Q K^T, P V and their gradients: 2 * 3 D S^2 forward, "
+             "2 * 7 D S^2 backward per example and layer) against the fp32 MFMA peak")
 
 # SURVEY.md 8(d) vocabulary presets.  "criteo-card": the 26 public Criteo-Kaggle cardinalities (C1..C26), all below the
 # 2^24 - 1 limit of ids that travel as fp32 (deepctr/models/basemodel.py:242) -- 33.8 M rows, 574 M parameters; the
@@ -73,12 +77,13 @@ WORKLOADS = {
 }
 
 
-def synthetic_batches(n_batches, batch, vocab, n_dense, seed):
-    """Criteo-shaped batches: Zipf-like ids floor(V*u^3), dense ~ U(0,1), y ~ Bern(0.25)."""
+def synthetic_batches(n_batches, batch, vocab, n_dense, seed, uniform=False):
+    """Criteo-shaped batches: Zipf-like ids floor(V*u^3) -- or uniform ids floor(V*u), the worst case for
+    every cache between the tables and the gather -- dense ~ U(0,1), y ~ Bern(0.25)."""
     rng = np.random.default_rng(seed)
     out = []
     for _ in range(n_batches):
-        ids = np.floor(np.asarray(vocab)[None, :] * rng.random((batch, len(vocab))) ** 3)
+        ids = np.floor(np.asarray(vocab)[None, :] * rng.random((batch, len(vocab))) ** (1 if uniform else 3))
         ids = np.minimum(ids, np.asarray(vocab)[None, :] - 1)
         dense = rng.random((batch, n_dense))
         X = np.concatenate([ids, dense], axis=1).astype(np.float32)
@@ -275,12 +280,12 @@ def main():
     class Run(object):
         """One model + its resident batches; every rank draws its own shard of the global batch (weak scaling)."""
 
-        def __init__(self, vocab, lazy_rows=False):
+        def __init__(self, vocab, lazy_rows=False, uniform=False):
             self.model = build_model(cfg, vocab, device, lazy_rows)
             self.model.train()
             self.n_res = 8
             self.batches = [(torch.from_numpy(X).to(device), torch.from_numpy(y).to(device)) for X, y in
-                            synthetic_batches(self.n_res, B, vocab, cfg["n_dense"], seed=2025 + rank)]
+                            synthetic_batches(self.n_res, B, vocab, cfg["n_dense"], seed=2025 + rank, uniform=uniform)]
             if dp is not None:
                 dp._n_global = B * world          # the scatter exchange needs the global split (equal shards)
             # untimed: the first steps of a batch shape run eagerly and the third one captures the HIP graph the
@@ -306,6 +311,8 @@ def main():
             if flush is not None:
                 flush()                                      # ... and pays everything its K steps deferred before the clock stops
             t_host = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            self.dt_local = time.perf_counter() - t0          # this rank's own time, before it waits for the others
             barrier()
             dt = time.perf_counter() - t0
             prof, ops.PROFILE = ops.PROFILE, None
@@ -327,8 +334,25 @@ def main():
     log("timed region done: %.3f ms/step (host enqueue %.3f ms/step, %s)" % (
         dt / args.steps * 1e3, t_host / args.steps * 1e3,
         "HIP graph replay, %d nodes" % max(e.nodes for e in run.gstep.entries.values()) if replayed else "eager launches"))
+    dt_local, host_local = run.dt_local, t_host
     # per-kernel device times for the roofline: the same steps from eager launches, HIP events around each launch
     _, _, prof = run.timed(min(args.steps, 10), 2, kernel_events=True)
+    per_rank = None
+    if world > 1:
+        # every rank's own view of the timed region, so that a scaling run explains itself: its wall time before the final
+        # barrier, its host time to enqueue a step (the second half of the row-parallel step is launched eagerly), and the
+        # device time of ITS scatter (K2 runs over the rows of all ranks on every rank) and gather launches
+        import torch.distributed as dist
+        mine = {"rank": rank, "ms_per_step": round(dt_local / args.steps * 1e3, 4), "host_ms_per_step": round(host_local / args.steps * 1e3, 4)}
+        agg = {}
+        for name, work, e0, e1 in prof:
+            if name.startswith("embed_"):
+                agg.setdefault(name.replace("[bytes]", ""), []).append(e0.elapsed_time(e1))
+        nprof = min(args.steps, 10)
+        for k, v in agg.items():
+            mine[k + "_ms_per_step"] = round(sum(v) / nprof, 4)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     alt = None
     if world == 1 and not args.no_alt:
         # the same K steps with the other arithmetic of the CIN contraction, for reference in the same line
@@ -340,6 +364,58 @@ def main():
                    ms_per_step=round(adt / args.steps * 1e3, 4), arithmetic=CIN_MATH[other][2])
         log("other arithmetic (%s): %.3f ms/step" % (CIN_MATH[other][0], adt / args.steps * 1e3))
     extras = {}
+    if world == 1 and not args.no_extras:
+        # (0a) one LONG timed region of the same replayed step (400 steps, the periodic flushes of the deferred update inside
+        # it and one at its end): the figure a 20-step region can only sample
+        ldt, _, _ = run.timed(400, 0)
+        extras["long_region"] = dict(steps=400, value=round(B * 400 / ldt, 1), unit="examples/sec", ms_per_step=round(ldt / 400 * 1e3, 4))
+        log("long region (400 steps): %.3f ms/step" % (ldt / 400 * 1e3))
+        # (0b) the reference's own loop around the step (basemodel.py:137-309 / :325-352): `fit` over 64 steps per epoch with
+        # the epoch-end flush and loss read-back (per epoch: the difference of a 3-epoch and a 1-epoch call, which removes
+        # the one-off host conversion of the inputs), and `predict` at the scripts' batch size 8192 (second call)
+        names = list(run.model.feature_index.keys())
+        Xf, yf = synthetic_batches(1, 64 * B, vocab, cfg["n_dense"], seed=77)[0]
+        data = {n: Xf[:, i] for i, n in enumerate(names)}
+
+        def fit_time(epochs):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):
+                run.model.fit(data, yf, batch_size=B, epochs=epochs, verbose=0, shuffle=False)
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        fit_time(1)
+        t1, t3 = fit_time(1), fit_time(3)
+        per_epoch = max((t3 - t1) / 2.0, 1e-9)
+        extras["fit_examples_per_sec"] = dict(value=round(64 * B / per_epoch, 1), unit="examples/sec", steps_per_epoch=64,
+                                              ms_per_step=round(per_epoch / 64 * 1e3, 4),
+                                              end_to_end_3_epochs=round(3 * 64 * B / t3, 1),
+                                              note="BaseModel.fit (verbose=0, shuffle=False): per epoch = (3-epoch call - 1-epoch call) / 2, "
+                                                   "epoch-end flush and loss read-back included; end_to_end also pays the host-side "
+                                                   "conversion of the numpy inputs")
+        npred = 262144
+        pdata = {n: Xf[:npred, i] for i, n in enumerate(names)}
+        run.model.predict(pdata, 8192)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run.model.predict(pdata, 8192)
+        torch.cuda.synchronize()
+        pt = time.perf_counter() - t0
+        extras["predict_examples_per_sec"] = dict(value=round(npred / pt, 1), unit="examples/sec", rows=npred, batch_size=8192,
+                                                  note="BaseModel.predict from numpy inputs to the float64 [N, 1] result on the host")
+        run.model.train()
+        log("fit: %.3f ms/step per epoch (%.0f ex/s), predict: %.0f ex/s" % (per_epoch / 64 * 1e3, 64 * B / per_epoch, npred / pt))
+        del Xf, yf, data, pdata
+        # (0c) the headline step on UNIFORM ids (the worst case for the gather / scatter / row-keyed optimizer)
+        uni = Run(vocab, uniform=True)
+        udt, _, _ = uni.timed(args.steps, args.warmup)
+        extras["uniform_ids"] = dict(value=round(B * args.steps / udt, 1), unit="examples/sec", ms_per_step=round(udt / args.steps * 1e3, 4),
+                                     note="same workload, ids ~ floor(V * u) instead of the Zipf-like floor(V * u^3)")
+        log("uniform ids: %.3f ms/step" % (udt / args.steps * 1e3))
+        del uni
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_extras and args.vocab <= 0 and preset == "criteo-card":
         # (1) the same step at the mid vocabulary (1e5 rows per field: round 1's headline): what the step costs when the
         # dense-Adam table sweep is small;  (2) the criteo-card step with the OPT-IN row-sparse ("lazy") Adam, which is
@@ -395,19 +471,31 @@ def main():
                 per_kernel[name] = [secs * prof_steps, work * prof_steps, len(ev)]
             else:
                 per_kernel[name] = [sum(t for t, _ in ev), sum(w for _, w in ev), len(ev)]
-        mfma = {k: v for k, v in per_kernel.items() if k.startswith("cin_level") and not k.endswith("passes")}
+        # the DOMINANT bracketed kernel by summed device time, whatever it is (CIN contraction, attention block, gather,
+        # scatter, optimizer), against the roofline that bounds it
+        cands = {k: v for k, v in per_kernel.items() if v[1] > 0 and not k.endswith("passes")}
         roof = None
-        if mfma:
-            name, (secs, flops, n) = max(mfma.items(), key=lambda kv: kv[1][0])
-            achieved = flops / secs / 1e12
-            peak = CIN_MATH[math_mode][1]
-            roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1),
-                        unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
-                        launches=n, avg_ms=round(secs / n * 1e3, 4),
-                        note="fp32-equivalent FLOPs of the reference's contraction (2*H*Hp*m*N per launch); level 0 "
-                             "(x_prev is x0) contracts over the pairs i <= j with folded weights and issues about half (50-54 %) "
-                             "of the MFMAs counted here for it; " + CIN_MATH[math_mode][2])
-            roof.update(pmc_traffic(name, args.workload, math_mode))
+        if cands:
+            name, (secs, work, n) = max(cands.items(), key=lambda kv: kv[1][0])
+            if name.endswith("[bytes]"):
+                achieved, peak = work / secs / 1e9, HBM_PEAK_GBS
+                roof = dict(kernel=name.replace("[bytes]", ""), bound="hbm", achieved=round(achieved, 1), peak=peak, unit="GB/s",
+                            frac=round(achieved / peak, 4), traffic=None, launches=n, avg_ms=round(secs / n * 1e3, 4),
+                            note="algorithmic bytes per launch (SURVEY.md 8d) / measured launch time")
+            elif name.startswith("cin_attn_pool"):
+                achieved, peak = work / secs / 1e12, ATTN_PEAK_TFLOPS
+                roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
+                            frac=round(achieved / peak, 4), traffic=None, launches=n, avg_ms=round(secs / n * 1e3, 4), note=ATTN_NOTE)
+            else:
+                achieved = work / secs / 1e12
+                peak = CIN_MATH[math_mode][1]
+                roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1),
+                            unit="TFLOP/s", frac=round(achieved / peak, 4), traffic=None,
+                            launches=n, avg_ms=round(secs / n * 1e3, 4),
+                            note="fp32-equivalent FLOPs of the reference's contraction (2*H*Hp*m*N per launch); level 0 "
+                                 "(x_prev is x0) contracts over the pairs i <= j with folded weights and issues about half (50-54 %) "
+                                 "of the MFMAs counted here for it; " + CIN_MATH[math_mode][2])
+                roof.update(pmc_traffic(name, args.workload, math_mode))
         kernels = {}
         calls_per_step = {k: v[2] / prof_steps for k, v in per_kernel.items()}
         for k, v in sorted(per_kernel.items()):
@@ -415,7 +503,7 @@ def main():
             kernels[k.replace("[bytes]", "")] = dict(
                 ms_per_step=round(v[0] / max(v[2], 1) * calls_per_step[k] * 1e3, 4),
                 **({"GBps": round(rate / 1e9, 1), "frac_hbm": round(rate / 1e9 / HBM_PEAK_GBS, 4)}
-                   if k.endswith("[bytes]") else ({} if k.endswith("passes") else {"TFLOPs": round(rate / 1e12, 2)})))
+                   if k.endswith("[bytes]") else ({} if (k.endswith("passes") or v[1] <= 0) else {"TFLOPs": round(rate / 1e12, 2)})))
         if getattr(run.model.optim, "_def", None) is not None and "adam_step" in kernels:
             # deferred table update: no sweep to price in GB/s -- these are the step's own optimizer kernels (dense weights,
             # small-table mark scan, big tables by the batch's rows); the catch-up before the gather and the periodic flush
@@ -461,6 +549,8 @@ def main():
         if ranks_seen is not None:
             out["ranks_seen"] = ranks_seen
             out["backend"] = args.backend
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if alt is not None:
             out["other_arithmetic"] = alt
         if world == 1 and not args.no_cpu_baseline:

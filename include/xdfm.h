@@ -35,7 +35,7 @@
  * ABI 7: xdfm_cin_bwd_x_is_folded (a pure query instead of the "last_sym" probe on the product path); the deferred update's
  * constant table holds 4 floats per step (xdfm_adam_clock.consts: 4 * cap) and its replayed steps run the short forms of
  * csrc/adam_math.h (same bits, about half the issue slots); xdfm_adam_selftest; xdfm_cin_bwd_prep +
- * xdfm_cin_level_bwd_w_prepared (dOut, its fp16 planes and the dW kernel's scales in one pass).
+ * xdfm_cin_level_bwd_w_prepared (dOut, its fp16 planes and the dW kernel's scales in one pass); xdfm_set_ticket_board.
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -90,6 +90,12 @@ int xdfm_device_count(void);                /* <0: HIP error code negated */
  * a shape without a kernel in the selected mode runs mode 0, and the tests assert which one ran. */
 int xdfm_set_option(const char* key, int value);
 int xdfm_get_option(const char* key);
+/* Ticket board: `board` = a DEVICE array of `slots` >= 1040 unsigned ints, zeroed once by the caller and kept alive, registered
+ * for the CURRENT device (NULL unregisters).  With a board, every kernel of the library that leaves per-block partials lets
+ * the block that finishes last add them up (in the same fixed order) instead of a one-block "finish" launch of its own:
+ * ten launches fewer per train step, identical results.  The kernels reset the tickets they use; one calling thread and
+ * one stream per device at a time (as for the rest of the library). */
+int xdfm_set_ticket_board(unsigned* board, int slots);
 /* [host] node types of a captured hipGraph_t (the host side replays the train step from a HIP graph):
  * memset nodes are counted separately because they are not ordered reliably against neighbouring kernel
  * nodes on ROCm 7.2 / gfx950 (tools/graph_memset_probe.py) -- a graph with n_memset > 0 must not be replayed;
@@ -332,7 +338,7 @@ int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, const f
  * replaces: torch.optim.Adam.step() (deepctr/models/basemodel.py:452).  The embedding / linear tables carry
  * dense gradients (deepctr/inputs.py:168), so the step streams every parameter: 28 B per parameter, arithmetic
  * of ATen's fused Adam in fp32.  `tensors` is a HOST array of T descriptors (device pointers inside; they travel
- * by value in the kernel arguments, 40 per launch); `step` points to the fp32 step counter torch keeps per
+ * by value in the kernel arguments, 52 per launch); `step` points to the fp32 step counter torch keeps per
  * parameter, already incremented for this step.
  * l2 > 0 in a descriptor: the kernel uses g + 2*l2*w as the gradient (the term l2 * sum(w^2) of
  * basemodel.py:412-428 with unit upstream gradient); with l2_value != NULL it also returns

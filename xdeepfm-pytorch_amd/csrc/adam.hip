@@ -1,4 +1,4 @@
-// K7: Adam step over all parameters (one launch per 40 tensors, a 1-D grid shared out by tensor size; the embedding
+// K7: Adam step over all parameters (one launch per 52 tensors, a 1-D grid shared out by tensor size; the embedding
 // tables are 98 % of the bytes).
 //
 // replaces torch.optim.Adam.step() for the [vocab, D] / [vocab, 1] tables (deepctr/models/basemodel.py:452
@@ -50,16 +50,28 @@ __device__ __forceinline__ void adam_st(float4* a, const float4& x) {
 
 #define ADAM_FIX 1099511627776.0          // 2^40: fixed-point scale of the L2 backlog (integer adds: order-independent)
 
-#define ADAM_CHUNK 40
+#define ADAM_CHUNK 64
 // first[k] = first block of tensor k in the launch's 1-D grid (first[cnt] = grid size): a tensor's share of the grid
 // follows its size, so a launch that holds four 10 M-row tables and thirty small tensors is 16 000 blocks of table
 // sweep, not 128 per tensor
-struct AdamBatch { xdfm_adam_tensor t[ADAM_CHUNK]; int first[ADAM_CHUNK + 1]; };
+// the descriptor as the kernels see it: 72 bytes, so that 52 of them (the criteo-card step holds 51 tensors outside the
+// by-rows tables: one launch instead of two 35-us launches of small, latency-bound tensors) and the other arguments stay
+// inside the 4 KB a kernel's argument block may take
+struct AdamDev {
+    float* param; float* grad; float* exp_avg; float* exp_avg_sq; const float* step; unsigned char* grad_marks; unsigned char* last;
+    long numel; float l2; int flags;
+};
+static inline AdamDev adam_dev(const xdfm_adam_tensor& t) {
+    return AdamDev{t.param, t.grad, t.exp_avg, t.exp_avg_sq, t.step, t.grad_marks, t.last, t.numel, t.l2, t.flags};
+}
+struct AdamBatch { AdamDev t[ADAM_CHUNK]; int first[ADAM_CHUNK + 1]; };
+static_assert(sizeof(AdamBatch) + 128 <= 8192, "the Adam kernels' argument block");
 
 template <bool NT>
 __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
     const AdamBatch batch, int cnt, int slot0, double lr_arg, const double* __restrict__ lr_dev, double beta1, double beta2, double eps,
-    float* __restrict__ l2_part, const int* __restrict__ clock, const float* __restrict__ consts) {
+    float* __restrict__ l2_part, const int* __restrict__ clock, const float* __restrict__ consts, float* __restrict__ l2_out,
+    int l2_total, unsigned* __restrict__ ticket) {
     // the learning rate as a kernel argument, or read from device memory (a captured HIP graph then follows a
     // learning-rate schedule without being captured again)
     const double lr = lr_dev ? *lr_dev : lr_arg;
@@ -67,7 +79,7 @@ __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
     for (int k = 1; k < cnt; ++k) ti += (int)blockIdx.x >= batch.first[k] ? 1 : 0;
     const int lb = (int)blockIdx.x - batch.first[ti];  // this block among the tensor's nb blocks
     const int nb = batch.first[ti + 1] - batch.first[ti];
-    const xdfm_adam_tensor& d = batch.t[ti];
+    const AdamDev& d = batch.t[ti];
     float* __restrict__ p = d.param;
     float* __restrict__ m = d.exp_avg;
     float* __restrict__ v = d.exp_avg_sq;
@@ -289,7 +301,21 @@ __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sq;
         __syncthreads();
         // one slot per block of the step, in launch order: the finish kernel adds them in that fixed order
-        if (threadIdx.x == 0) l2_part[slot0 + blockIdx.x] = l2c * ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+        if (threadIdx.x == 0) xdfm_publish(&l2_part[slot0 + blockIdx.x], l2c * ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])));
+        // the step's last launch: its last block adds up the partials of ALL launches (the earlier ones are complete: stream
+        // order), in slot order -- what adam_l2_finish_kernel does in a launch of its own
+        if (ticket && xdfm_last_block_done(ticket, gridDim.x)) {
+            __shared__ float acc[ADAM_THREADS];
+            float v = 0.f;
+            for (int k = threadIdx.x; k < l2_total; k += ADAM_THREADS) v += xdfm_peer(l2_part + k);
+            acc[threadIdx.x] = v;
+            __syncthreads();
+            for (int o = ADAM_THREADS / 2; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) acc[threadIdx.x] += acc[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) l2_out[0] = acc[0];
+        }
     }
 }
 
@@ -433,7 +459,8 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_catchup_rows_kernel(
 __global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
     const float* __restrict__ X, long ldx, int B, const int* __restrict__ cols, const int* __restrict__ vocab, int m, int D,
     AdamRowsDev emb, AdamRowsDev lin, int has_lin, const int* __restrict__ clock, const float* __restrict__ consts,
-    double beta1, double beta2, double eps, unsigned long long* __restrict__ cell) {
+    double beta1, double beta2, double eps, unsigned long long* __restrict__ cell, float* __restrict__ l2_value,
+    unsigned* __restrict__ ticket) {
     const int t = clock[0];
     const int QE = (D + 3) / 4 + ((D & 3) ? 1 : 0);
     const int QT = QE + (has_lin ? 1 : 0);
@@ -500,6 +527,12 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
         }
     }
     adam_backlog_add(sqv, cell);
+    // adam_rows_finish_kernel's job, by the block that finishes last (every block's integer add is in `cell` by then)
+    if (ticket && xdfm_last_block_done(ticket, gridDim.x) && threadIdx.x == 0) {
+        const unsigned long long tot = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (l2_value) l2_value[0] += (float)((double)(long long)tot / ADAM_FIX);
+        __hip_atomic_store(cell, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 __global__ void adam_rows_finish_kernel(unsigned long long* __restrict__ cell, float* __restrict__ l2_value) {
@@ -517,7 +550,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_flush_kernel(const AdamBatc
     for (int k = 1; k < cnt; ++k) ti += (int)blockIdx.x >= batch.first[k] ? 1 : 0;
     const int lb = (int)blockIdx.x - batch.first[ti];
     const int nb = batch.first[ti + 1] - batch.first[ti];
-    const xdfm_adam_tensor& d = batch.t[ti];
+    const AdamDev& d = batch.t[ti];
     const int t = clock[0];
     float4* p4 = reinterpret_cast<float4*>(d.param);
     float4* m4 = reinterpret_cast<float4*>(d.exp_avg);
@@ -696,6 +729,7 @@ static int adam_step_impl(const xdfm_adam_tensor* tensors, int T, const xdfm_ada
     // its share of the big tables and the small tensors' latency-bound blocks run underneath (a launch of small
     // tensors alone took 25 us for 30 MB).  The order is a pure function of the sizes: deterministic.
     const int nlaunch = ceil_div(T, ADAM_CHUNK);
+    unsigned* ticket = xdfm_ticket(TK_ADAM_L2);
     std::vector<int> order(T);
     for (int t = 0; t < T; ++t) order[t] = t;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tensors[a].numel > tensors[b].numel; });
@@ -703,7 +737,7 @@ static int adam_step_impl(const xdfm_adam_tensor* tensors, int T, const xdfm_ada
     for (int l = 0; l < nlaunch; ++l) {
         AdamBatch batch;
         int cnt = 0;
-        for (int k = l; k < T; k += nlaunch) batch.t[cnt++] = tensors[order[k]];
+        for (int k = l; k < T; k += nlaunch) batch.t[cnt++] = adam_dev(tensors[order[k]]);
         for (int k = cnt; k < ADAM_CHUNK; ++k) batch.t[k] = batch.t[0];
         // blocks per tensor by size (option "adam_bx" caps them: a small footprint for experiments)
         int cap = xdfm_opt(OPT_ADAM_BX);
@@ -715,15 +749,17 @@ static int adam_step_impl(const xdfm_adam_tensor* tensors, int T, const xdfm_ada
             if (nb > cap) nb = cap;
             batch.first[k + 1] = batch.first[k] + (int)nb;
         }
+        unsigned* tk = (l2_value && l == nlaunch - 1) ? ticket : nullptr;
+        const int l2_total = slot0 + batch.first[cnt];
         if (xdfm_opt(OPT_DBG) & (1 << 17))              // experiment: ordinary (cached) loads and stores
             hipLaunchKernelGGL(adam_step_kernel<false>, dim3(batch.first[cnt]), dim3(ADAM_THREADS), 0, st, batch, cnt, slot0, lr,
-                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr, clock, consts);
+                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr, clock, consts, l2_value, l2_total, tk);
         else
             hipLaunchKernelGGL(adam_step_kernel<true>, dim3(batch.first[cnt]), dim3(ADAM_THREADS), 0, st, batch, cnt, slot0, lr,
-                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr, clock, consts);
+                               lr_dev, beta1, beta2, eps, l2_value ? l2_ws : nullptr, clock, consts, l2_value, l2_total, tk);
         slot0 += batch.first[cnt];
     }
-    if (l2_value) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(1024), 0, st, l2_ws, slot0, l2_value);
+    if (l2_value && !ticket) hipLaunchKernelGGL(adam_l2_finish_kernel, dim3(1), dim3(1024), 0, st, l2_ws, slot0, l2_value);
     return xdfm_check_launch("adam_step");
 }
 
@@ -755,10 +791,12 @@ int xdfm_adam_apply_rows(const float* X, long ldx, int B, const int* cols, const
     const int QT = (D + 3) / 4 + ((D & 3) ? 1 : 0) + (lin ? 1 : 0);
     const long threads = (long)B * m * QT + 8L * m;
     hipStream_t st = (hipStream_t)stream;
+    unsigned* ticket = nullptr;      // thousands of blocks: the finish stays a launch of its own (tickets on one address serialise)
     hipLaunchKernelGGL(adam_apply_rows_kernel, dim3((unsigned)ceil_div(threads, (long)ADAM_THREADS)), dim3(ADAM_THREADS), 0, st, X, ldx,
                        B, cols, vocab, m, D, e, l, lin ? 1 : 0, clk->clock, clk->consts, beta1, beta2, eps,
-                       reinterpret_cast<unsigned long long*>(l2_cell));
-    hipLaunchKernelGGL(adam_rows_finish_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(l2_cell), l2_value);
+                       reinterpret_cast<unsigned long long*>(l2_cell), l2_value, ticket);
+    if (!ticket)
+        hipLaunchKernelGGL(adam_rows_finish_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(l2_cell), l2_value);
     return xdfm_check_launch("adam_apply_rows");
 }
 
@@ -778,7 +816,7 @@ int xdfm_adam_flush(const xdfm_adam_tensor* tensors, int T, const xdfm_adam_cloc
     for (int l0 = 0; l0 < n; l0 += ADAM_CHUNK) {
         AdamBatch batch;
         const int cnt = n - l0 < ADAM_CHUNK ? n - l0 : ADAM_CHUNK;
-        for (int k = 0; k < ADAM_CHUNK; ++k) batch.t[k] = tensors[order[l0 + (k < cnt ? k : 0)]];
+        for (int k = 0; k < ADAM_CHUNK; ++k) batch.t[k] = adam_dev(tensors[order[l0 + (k < cnt ? k : 0)]]);
         batch.first[0] = 0;
         for (int k = 0; k < ADAM_CHUNK; ++k) {
             long nb = k < cnt ? ceil_div(batch.t[k].numel, (long)ADAM_BLOCK_ELEMS) : 0;

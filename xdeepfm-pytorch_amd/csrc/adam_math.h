@@ -122,8 +122,9 @@ __device__ __forceinline__ void adam_replay4(float4& p, float4& m, float4& v, co
         const adam_f2 E = {c.eps, c.eps}, SS = {k.ss, k.ss};
         const adam_f2 sa = adam_sqrt_scaled2(va1 * big), sb = adam_sqrt_scaled2(vb1 * big);
         const adam_f2 da = adam_div_const2(sa, k.c2, k.rc2) + E, db = adam_div_const2(sb, k.c2, k.rc2) + E;
-        pa -= adam_div2(SS * ma1, da);
-        pb -= adam_div2(SS * mb1, db);
+        const adam_f2 neg1 = {-1.f, -1.f};                  // p - q as fma(q, -1, p): the same single rounding, one packed instruction
+        pa = adam_pkfma(adam_div2(SS * ma1, da), neg1, pa);
+        pb = adam_pkfma(adam_div2(SS * mb1, db), neg1, pb);
         p = make_float4(pa.x, pa.y, pb.x, pb.y);
         m = make_float4(ma1.x, ma1.y, mb1.x, mb1.y);
         v = make_float4(va1.x, va1.y, vb1.x, vb1.y);

@@ -34,6 +34,14 @@ int xdfm_fail(int code, const char* fmt, ...) {
 }
 
 int xdfm_opt(int idx) { return g_opts[idx]; }
+
+#define XDFM_MAX_DEVICES 16
+static unsigned* g_ticket_board[XDFM_MAX_DEVICES] = {nullptr};
+unsigned* xdfm_ticket(int slot) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= XDFM_MAX_DEVICES || !g_ticket_board[dev]) return nullptr;
+    return g_ticket_board[dev] + slot;
+}
 void xdfm_opt_note(int idx, int value) { g_opts[idx] = value; }
 
 extern "C" {
@@ -68,6 +76,16 @@ int xdfm_graph_node_census(void* graph, int* n_nodes, int* n_memset, int* n_unex
     free(nodes);
     if (e != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "graph_node_census: %s", hipGetErrorString(e));
     *n_nodes = (int)n; *n_memset = ms; *n_unexpected = other;
+    return XDFM_OK;
+}
+
+int xdfm_set_ticket_board(unsigned* board, int slots) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return xdfm_fail(XDFM_ERR_NO_DEVICE, "set_ticket_board: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= XDFM_MAX_DEVICES) return xdfm_fail(XDFM_ERR_INVALID, "set_ticket_board: device %d", dev);
+    if (board && slots < TK_COUNT) return xdfm_fail(XDFM_ERR_INVALID, "set_ticket_board: %d slots, %d needed", slots, TK_COUNT);
+    g_ticket_board[dev] = board;
     return XDFM_OK;
 }
 

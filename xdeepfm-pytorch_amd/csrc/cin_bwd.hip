@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
     const float* __restrict__ A, int H, long N, int D, int act,
     const float* __restrict__ dHid, int hid0, int hid_rows,
     const float* __restrict__ dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
-    float* __restrict__ dOut, float* __restrict__ dbias, float* __restrict__ slots) {
+    float* __restrict__ dOut, float* __restrict__ dbias, float* __restrict__ slots, unsigned* __restrict__ ticket) {
     const int h = blockIdx.y;
     const bool has_hid = dHid && h >= hid0 && h < hid0 + hid_rows;
     const bool has_dir = dDir && h >= dir0 && h < dir0 + dir_rows;
@@ -75,8 +75,14 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
         const float bsum = wsum[0] + wsum[1] + wsum[2] + wsum[3];
         // with a workspace: one slot per block, added up in block order by cin_dbias_finish_kernel (the same bits on
         // every run); without: a float atomic per block, whose order -- and with it the last bits -- varies
-        if (slots) slots[(long)h * gridDim.x + blockIdx.x] = bsum;
+        if (slots) xdfm_publish(&slots[(long)h * gridDim.x + blockIdx.x], bsum);
         else atomicAdd(&dbias[h], bsum);
+    }
+    // the last block of this ROW adds the row's slots up, in block order (one ticket per row)
+    if (slots && ticket && xdfm_last_block_done(ticket + h, gridDim.x) && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < (int)gridDim.x; ++k) s += xdfm_peer(slots + (long)h * gridDim.x + k);
+        dbias[h] += s;
     }
 }
 
@@ -770,13 +776,14 @@ int xdfm_cin_dout_det(const float* A, int H, int B, int D, int act, const float*
     const float* dd = dir_rows > 0 ? dDir : nullptr;
     const bool vec = cin_dout_vec(A, N, D, dOut, dh, dd);
     const int gx = ceil_div(N, vec ? 4096 : 1024);
+    unsigned* ticket = (ws && H <= TK_ROWS) ? xdfm_ticket(TK_ROW0) : nullptr;
     if (vec)
         hipLaunchKernelGGL(cin_dout_kernel<4>, dim3(gx, H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
-                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws);
+                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws, ticket);
     else
         hipLaunchKernelGGL(cin_dout_kernel<1>, dim3(gx, H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
-                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws);
-    if (ws) hipLaunchKernelGGL(cin_dbias_finish_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, (hipStream_t)stream, ws, H, gx, dbias);
+                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws, ticket);
+    if (ws && !ticket) hipLaunchKernelGGL(cin_dbias_finish_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, (hipStream_t)stream, ws, H, gx, dbias);
     return xdfm_check_launch("cin_dout");
 }
 
@@ -891,11 +898,13 @@ int xdfm_cin_bwd_prep(const float* A, int H, int B, int D, int act, const float*
                  "cin_bwd_prep: row ranges outside [0,%d)", H);
     XDFM_REQUIRE(dir_mode == 0 || dir_mode == 1, "cin_bwd_prep: dir_mode %d", dir_mode);
     hipStream_t st = (hipStream_t)stream;
-    int rc = x3_bwd_prep(A, H, N, D, act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dout_ws, xp, x0,
-                         Hp, m, bww_ws, st);
+    unsigned* ticket = H <= TK_ROWS ? xdfm_ticket(TK_ROW0) : nullptr;
+    int rc = x3_bwd_prep(A, H, N, D, act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dout_ws, dbias,
+                         ticket, xp, x0, Hp, m, bww_ws, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(cin_dbias_finish_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, st, dout_ws, H,
-                       x3_bwd_prep_blocks(xp == x0, H, Hp, m, N), dbias);
+    if (!ticket)
+        hipLaunchKernelGGL(cin_dbias_finish_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, st, dout_ws, H,
+                           x3_bwd_prep_blocks(xp == x0, H, Hp, m, N), dbias);
     *prepared = 1;
     return xdfm_check_launch("cin_bwd_prep");
 }

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
     const float* __restrict__ A, int H, long N, X3Magic divD, int act,
     const float* __restrict__ dHid, int hid0, int hid_rows,
     const float* __restrict__ dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
-    float* __restrict__ dOut, float* __restrict__ slots,
+    float* __restrict__ dOut, float* __restrict__ slots, float* __restrict__ dbias, unsigned* __restrict__ ticket,
     const float* __restrict__ xp, const float* __restrict__ x0, int Hp, int m, int Hpad, int IPAD,
     int n_per_split, X3Magic divS, int KS, int nsplit, float* __restrict__ hdr2, long HS, char* __restrict__ planes, long NP) {
     __shared__ unsigned seg_max[X3_PREP_COLS / 32 + 1];
@@ -638,10 +638,14 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
             if (!(av.w > 0.f)) g.w = 0.f;
         }
     };
-    auto account = [&](int o, const float4& g0, const float4& g1) {       // dOut store, dbias share, split maximum of 8 columns
+    // dbias share and split maximum of 8 columns; the dOut store too when the values do not stay in registers (otherwise it
+    // waits until the block has drawn its ticket: a block's ticket waits for its outstanding stores, see `finish`)
+    auto account = [&](int o, const float4& g0, const float4& g1) {
         if (is_d) {
-            *reinterpret_cast<float4*>(orow + o) = g0;
-            if (o + 4 < nreal) *reinterpret_cast<float4*>(orow + o + 4) = g1;
+            if (!reg) {
+                *reinterpret_cast<float4*>(orow + o) = g0;
+                if (o + 4 < nreal) *reinterpret_cast<float4*>(orow + o + 4) = g1;
+            }
             part += ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w));
         }
         if (NT == 3) {
@@ -653,12 +657,8 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
     };
     // `account` when the whole wave is inside the block's columns: the wave's 512 columns usually lie in ONE split, and
     // then one lane speaks for all 64 (64 LDS atomics on one address take 64 turns)
-    auto account_wave = [&](int o, const float4& g0, const float4& g1) {
-        if (is_d) {
-            *reinterpret_cast<float4*>(orow + o) = g0;
-            *reinterpret_cast<float4*>(orow + o + 4) = g1;
-            part += ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w));
-        }
+    auto account_wave = [&](int o, const float4& g0, const float4& g1) {          // (only in the register path)
+        if (is_d) part += ((g0.x + g0.y) + (g0.z + g0.w)) + ((g1.x + g1.y) + (g1.z + g1.w));
         if (NT == 3) {
             float mx = fmaxf(fmaxf(fmaxf(fabsf(g0.x), fabsf(g0.y)), fmaxf(fabsf(g0.z), fabsf(g0.w))),
                              fmaxf(fmaxf(fabsf(g1.x), fabsf(g1.y)), fmaxf(fabsf(g1.z), fabsf(g1.w))));
@@ -751,12 +751,20 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
     // would wait for every one of them to be acknowledged before the first plane store goes out)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (is_d && real && threadIdx.x == 0) slots[(long)row * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (is_d && real && threadIdx.x == 0) xdfm_publish(&slots[(long)row * gridDim.x + blockIdx.x], (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
     // the splits' scales: dOut rows < 2^15, x_prev / x0 rows < 2^7 (|Z| < 2^14); 1 for padding rows and for bf16
     const int target = is_d ? 15 : 7;
     for (int k = threadIdx.x; k < ns; k += 256) {
         const float sc = (NT == 3 && real) ? x3w_pow2_scale(__uint_as_float(seg_max[k]), target) : 1.f;
         hdr2[(long)(s0 + k) * HS + y] = sc;
+    }
+    // dbias: the block that draws the last ticket of a ROW adds the row's slots, in block order (no launch of its own for
+    // that).  The ticket is drawn HERE, before the block's dOut / plane stores go out: drawing it waits for the block's
+    // outstanding memory operations, and behind 48 KB of stores that wait kept every block on its CU for microseconds.
+    if (ticket && is_d && real && xdfm_last_block_done(ticket + row, gridDim.x) && threadIdx.x == 0) {     // one ticket per dOut row
+        float sacc = 0.f;
+        for (int k = 0; k < (int)gridDim.x; ++k) sacc += xdfm_peer(slots + (long)row * gridDim.x + k);
+        dbias[row] += sacc;
     }
     if (!is_d) return;
     // planes of this row and these columns: [hi 32 halves | lo 32 halves] per 32 columns, zero beyond N and for rows >= H
@@ -787,6 +795,10 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
         char* blk = prow + (long)(o & ~31) * 4 + (o & 31) * 2;
         *reinterpret_cast<h8*>(blk) = hi;
         if (NT == 3) *reinterpret_cast<h8*>(blk + 64) = lo;
+        if (reg && real && o < nreal) {                               // the fp32 dOut the dX kernel reads
+            *reinterpret_cast<float4*>(orow + o) = g0;
+            if (o + 4 < nreal) *reinterpret_cast<float4*>(orow + o + 4) = g1;
+        }
     }
 }
 
@@ -806,8 +818,8 @@ int x3_bwd_prep_blocks(bool xp_is_x0, int H, int Hp, int m, long N) {
 }
 
 int x3_bwd_prep(const float* A, int H, long N, int D, int act, const float* dHid, int hid0, int hid_rows, const float* dDir,
-                int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut, float* slots, const float* xp,
-                const float* x0, int Hp, int m, float* ws, hipStream_t st) {
+                int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut, float* slots, float* dbias,
+                unsigned* ticket, const float* xp, const float* x0, int Hp, int m, float* ws, hipStream_t st) {
     const int NW = x3_bww_waves();
     bool sym;
     const BwwGeom g = x3_bww_launch_geometry(xp, x0, H, Hp, m, N, NW, &sym);
@@ -822,11 +834,11 @@ int x3_bwd_prep(const float* A, int H, long N, int D, int act, const float* dHid
     const X3Magic divD = x3_magic(D), divS = x3_magic(g.n_per_split);
     if (x3_terms() == 3)
         hipLaunchKernelGGL(x3_bwd_prep_kernel<3>, grid, dim3(256), 0, st, A, H, N, divD, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir,
-                           dir_off, dir0, dir_rows, dOut, slots, xp, x0, Hp, m, g.Hpad, g.IPAD, (int)g.n_per_split, divS, KS, g.nsplit, hdr2,
+                           dir_off, dir0, dir_rows, dOut, slots, dbias, ticket, xp, x0, Hp, m, g.Hpad, g.IPAD, (int)g.n_per_split, divS, KS, g.nsplit, hdr2,
                            w.HS, planes, w.NP);
     else
         hipLaunchKernelGGL(x3_bwd_prep_kernel<1>, grid, dim3(256), 0, st, A, H, N, divD, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir,
-                           dir_off, dir0, dir_rows, dOut, slots, xp, x0, Hp, m, g.Hpad, g.IPAD, (int)g.n_per_split, divS, KS, g.nsplit, hdr2,
+                           dir_off, dir0, dir_rows, dOut, slots, dbias, ticket, xp, x0, Hp, m, g.Hpad, g.IPAD, (int)g.n_per_split, divS, KS, g.nsplit, hdr2,
                            w.HS, planes, w.NP);
     return xdfm_check_launch("cin_bwd_prep (f16x3 / bf16)");
 }

@@ -124,8 +124,25 @@ int xdfm_l2_reg_bwd(const float* const* ptrs, const long* numel, const float* co
 // (tools/graph_memset_probe.py: 3 of 4 replays wrong), so the train step uses this two-launch,
 // atomics-free, fixed-order version instead.
 #define CS_ROWBLK 64
+// the CS_ROWBLK partials of every column, summed in the order of colsum_finish_kernel (4 groups of 16, then the groups),
+// by the block that finished last (xdfm_last_block_done): same bits, no launch of its own
+__device__ __forceinline__ void colsum_finish_all(const float* __restrict__ part, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 64 + threadIdx.x;                      // the 64 columns of this column block
+    if (threadIdx.x < 64 && c < cols) {
+        float s[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[q] = 0.f;
+#pragma unroll
+            for (int k = 0; k < CS_ROWBLK / 4; ++k) s[q] += xdfm_peer(part + (long)(q * (CS_ROWBLK / 4) + k) * cols + c);
+        }
+        out[c] = (s[0] + s[1]) + (s[2] + s[3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ g, long rows, int cols, long ld,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, float* __restrict__ out,
+                                                            unsigned* __restrict__ ticket) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rg = threadIdx.x >> 6;                         // 4 row groups per block
     const long per = (rows + CS_ROWBLK - 1) / CS_ROWBLK;
@@ -144,14 +161,16 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     red[rg][threadIdx.x & 63] = a;
     __syncthreads();
     if (rg == 0 && c < cols)
-        part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        xdfm_publish(&part[(long)blockIdx.y * cols + c], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (ticket && xdfm_last_block_done(ticket + blockIdx.x, gridDim.y)) colsum_finish_all(part, cols, out);      // one ticket per column block
 }
 
 // same walk with the ReLU mask applied on the way: gz = (y > 0) ? g : 0 is written out (the operand of the two
 // backward GEMMs of a dense layer) and summed (its bias gradient) -- threshold_backward + column sum in one pass
 __global__ __launch_bounds__(256) void relu_bwd_colsum_partial_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                                      long rows, int cols, long ldg, long ldy,
-                                                                     float* __restrict__ gz, float* __restrict__ part) {
+                                                                     float* __restrict__ gz, float* __restrict__ part,
+                                                                     float* __restrict__ out, unsigned* __restrict__ ticket) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rg = threadIdx.x >> 6;
     const long per = (rows + CS_ROWBLK - 1) / CS_ROWBLK;
@@ -180,7 +199,8 @@ __global__ __launch_bounds__(256) void relu_bwd_colsum_partial_kernel(const floa
     red[rg][threadIdx.x & 63] = a;
     __syncthreads();
     if (rg == 0 && c < cols)
-        part[(long)blockIdx.y * cols + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        xdfm_publish(&part[(long)blockIdx.y * cols + c], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    if (ticket && xdfm_last_block_done(ticket + blockIdx.x, gridDim.y)) colsum_finish_all(part, cols, out);      // one ticket per column block
 }
 
 // 64 columns per block, the CS_ROWBLK partials of a column summed by 4 threads in a fixed order
@@ -206,8 +226,9 @@ int xdfm_colsum(const float* g, long rows, int cols, long ld, float* ws, float* 
     XDFM_REQUIRE(g && ws && out, "colsum: null pointer");
     XDFM_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "colsum: bad shape rows=%ld cols=%d ld=%ld", rows, cols, ld);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 64), CS_ROWBLK), dim3(256), 0, st, g, rows, cols, ld, ws);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, st, ws, cols, out);
+    unsigned* ticket = ceil_div(cols, 64) <= TK_ROWS ? xdfm_ticket(TK_ROW0) : nullptr;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 64), CS_ROWBLK), dim3(256), 0, st, g, rows, cols, ld, ws, out, ticket);
+    if (!ticket) hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, st, ws, cols, out);
     return xdfm_check_launch("colsum");
 }
 
@@ -216,9 +237,10 @@ int xdfm_relu_bwd_colsum(const float* g, const float* y, long rows, int cols, lo
     XDFM_REQUIRE(g && y && ws && gz && out, "relu_bwd_colsum: null pointer");
     XDFM_REQUIRE(rows > 0 && cols > 0 && ldg >= cols && ldy >= cols, "relu_bwd_colsum: bad shape rows=%ld cols=%d", rows, cols);
     hipStream_t st = (hipStream_t)stream;
+    unsigned* ticket = ceil_div(cols, 64) <= TK_ROWS ? xdfm_ticket(TK_ROW0) : nullptr;
     hipLaunchKernelGGL(relu_bwd_colsum_partial_kernel, dim3(ceil_div(cols, 64), CS_ROWBLK), dim3(256), 0, st, g, y, rows, cols,
-                       ldg, ldy, gz, ws);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, st, ws, cols, out);
+                       ldg, ldy, gz, ws, out, ticket);
+    if (!ticket) hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(cols, 64)), dim3(256), 0, st, ws, cols, out);
     return xdfm_check_launch("relu_bwd_colsum");
 }
 
@@ -266,7 +288,8 @@ template <bool VEC>
 __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(
     const float* __restrict__ lin, const float* __restrict__ u, const float* __restrict__ wu, int Ku,
     const float* __restrict__ v, const float* __restrict__ wv, int Kv, const float* __restrict__ bias,
-    const float* __restrict__ y, int B, float* __restrict__ pred, float* __restrict__ part) {
+    const float* __restrict__ y, int B, float* __restrict__ pred, float* __restrict__ part, float* __restrict__ loss,
+    unsigned* __restrict__ ticket) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float bv = bias ? bias[0] : 0.f;
     float acc = 0.f;
@@ -301,7 +324,17 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_fwd_kernel(
     __shared__ float red[4];
     if (lane == 0) red[wave] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) xdfm_publish(&part[blockIdx.x], (red[0] + red[1]) + (red[2] + red[3]));
+    if (ticket && xdfm_last_block_done(ticket, gridDim.x)) {         // the tree of head_fwd_finish_kernel, by the last block
+        __shared__ float tree[HEAD_BLOCKS];
+        if (threadIdx.x < HEAD_BLOCKS) tree[threadIdx.x] = xdfm_peer(part + threadIdx.x);
+        __syncthreads();
+        for (int o = HEAD_BLOCKS / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) tree[threadIdx.x] += tree[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loss[0] = tree[0];
+    }
 }
 
 __global__ __launch_bounds__(HEAD_BLOCKS) void head_fwd_finish_kernel(const float* __restrict__ part, float* __restrict__ loss) {
@@ -321,7 +354,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(
     const float* __restrict__ pred, const float* __restrict__ y, const float* __restrict__ gloss,
     const float* __restrict__ u, const float* __restrict__ wu, int Ku, const float* __restrict__ v,
     const float* __restrict__ wv, int Kv, int B, float* __restrict__ dlin, float* __restrict__ du,
-    float* __restrict__ dv, float* __restrict__ part) {
+    float* __restrict__ dv, float* __restrict__ part, float* __restrict__ grads, unsigned* __restrict__ ticket) {
     extern __shared__ float sm[];                 // [4 waves][Ku + Kv + 1]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int KT = Ku + Kv + 1;
@@ -349,7 +382,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_kernel(
     if (lane == 0) mine[Ku + Kv] = gsum;
     __syncthreads();
     for (int k = threadIdx.x; k < KT; k += HEAD_THREADS)
-        part[(long)blockIdx.x * KT + k] = (sm[k] + sm[KT + k]) + (sm[2 * KT + k] + sm[3 * KT + k]);
+        xdfm_publish(&part[(long)blockIdx.x * KT + k], (sm[k] + sm[KT + k]) + (sm[2 * KT + k] + sm[3 * KT + k]));
+    if (ticket && xdfm_last_block_done(ticket, gridDim.x))          // head_bwd_finish_kernel's sums, by the last block
+        for (int k = threadIdx.x; k < KT; k += HEAD_THREADS) {
+            float s = 0.f;
+            for (int b = 0; b < HEAD_BLOCKS; ++b) s += xdfm_peer(part + (long)b * KT + k);
+            grads[k] = s;
+        }
 }
 
 // vectorised variant (K % 4 == 0, K <= 512, 16-byte aligned): 16 lanes per row, 4 rows per wave at a time, float4
@@ -360,7 +399,7 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_vec_kernel(
     const float* __restrict__ pred, const float* __restrict__ y, const float* __restrict__ gloss,
     const float* __restrict__ u, const float* __restrict__ wu, int Ku, const float* __restrict__ v,
     const float* __restrict__ wv, int Kv, int B, float* __restrict__ dlin, float* __restrict__ du,
-    float* __restrict__ dv, float* __restrict__ part) {
+    float* __restrict__ dv, float* __restrict__ part, float* __restrict__ grads, unsigned* __restrict__ ticket) {
     extern __shared__ float sm[];                 // [4 waves][Ku + Kv + 1]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane & 15, grp = lane >> 4;
@@ -421,7 +460,13 @@ __global__ __launch_bounds__(HEAD_THREADS) void head_bwd_vec_kernel(
     if (lane == 0) mine[Ku + Kv] = gsum;
     __syncthreads();
     for (int k = threadIdx.x; k < KT; k += HEAD_THREADS)
-        part[(long)blockIdx.x * KT + k] = (sm[k] + sm[KT + k]) + (sm[2 * KT + k] + sm[3 * KT + k]);
+        xdfm_publish(&part[(long)blockIdx.x * KT + k], (sm[k] + sm[KT + k]) + (sm[2 * KT + k] + sm[3 * KT + k]));
+    if (ticket && xdfm_last_block_done(ticket, gridDim.x))          // head_bwd_finish_kernel's sums, by the last block
+        for (int k = threadIdx.x; k < KT; k += HEAD_THREADS) {
+            float s = 0.f;
+            for (int b = 0; b < HEAD_BLOCKS; ++b) s += xdfm_peer(part + (long)b * KT + k);
+            grads[k] = s;
+        }
 }
 
 __global__ void head_bwd_finish_kernel(const float* __restrict__ part, int KT, float* __restrict__ out) {
@@ -444,13 +489,14 @@ int xdfm_head_fwd(const float* lin, const float* u, const float* wu, int Ku, con
     const int ku = u ? Ku : 0, kv = v ? Kv : 0;
     const bool vec = ku % 4 == 0 && kv % 4 == 0 && ku <= 512 && kv <= 512 &&
                      ((((size_t)u) | ((size_t)v) | ((size_t)wu) | ((size_t)wv)) & 15) == 0;
+    unsigned* ticket = xdfm_ticket(TK_HEAD_FWD);
     if (vec)
         hipLaunchKernelGGL(head_fwd_kernel<true>, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), 0, st, lin, u, wu, ku, v, wv, kv,
-                           bias, y, B, pred, ws);
+                           bias, y, B, pred, ws, loss, ticket);
     else
         hipLaunchKernelGGL(head_fwd_kernel<false>, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), 0, st, lin, u, wu, ku, v, wv, kv,
-                           bias, y, B, pred, ws);
-    hipLaunchKernelGGL(head_fwd_finish_kernel, dim3(1), dim3(HEAD_BLOCKS), 0, st, ws, loss);
+                           bias, y, B, pred, ws, loss, ticket);
+    if (!ticket) hipLaunchKernelGGL(head_fwd_finish_kernel, dim3(1), dim3(HEAD_BLOCKS), 0, st, ws, loss);
     return xdfm_check_launch("head_fwd");
 }
 
@@ -466,13 +512,14 @@ int xdfm_head_bwd(const float* pred, const float* y, const float* gloss, const f
     hipStream_t st = (hipStream_t)stream;
     const bool vec = ku % 4 == 0 && kv % 4 == 0 && ku <= 512 && kv <= 512 &&
                      ((((size_t)u) | ((size_t)v) | ((size_t)wu) | ((size_t)wv) | ((size_t)du) | ((size_t)dv)) & 15) == 0;
+    unsigned* ticket = xdfm_ticket(TK_HEAD_BWD);
     if (vec)
         hipLaunchKernelGGL(head_bwd_vec_kernel, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), lds, st, pred, y, gloss, u, wu, ku, v,
-                           wv, kv, B, dlin, du, dv, ws);
+                           wv, kv, B, dlin, du, dv, ws, grads, ticket);
     else
         hipLaunchKernelGGL(head_bwd_kernel, dim3(HEAD_BLOCKS), dim3(HEAD_THREADS), lds, st, pred, y, gloss, u, wu, ku, v, wv,
-                           kv, B, dlin, du, dv, ws);
-    hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(ceil_div(KT, 256)), dim3(256), 0, st, ws, KT, grads);
+                           kv, B, dlin, du, dv, ws, grads, ticket);
+    if (!ticket) hipLaunchKernelGGL(head_bwd_finish_kernel, dim3(ceil_div(KT, 256)), dim3(256), 0, st, ws, KT, grads);
     return xdfm_check_launch("head_bwd");
 }
 

@@ -35,6 +35,42 @@ enum {
     OPT_COUNT
 };
 
+// Ticket board (api.hip, xdfm_set_ticket_board): a small zeroed device array the host registers once per device.  A kernel
+// that leaves per-block partials takes a ticket when a block is done; the block that draws the last one sums the
+// partials in their fixed order and resets the ticket -- the separate one-block "finish" launch (4-6 us of launch floor
+// each, ten of them per train step) disappears, the result keeps its bits.  One slot per kernel family: launches of a
+// family on one stream are ordered, so they can share it.  Without a board (nullptr) the finish kernels run as before.
+// Tickets are drawn with a device-scope atomic on ONE address, and those serialise (~4 ns each): a family whose grids hold
+// thousands of blocks gets one ticket per ROW of its grid instead (TK_ROWS slots from TK_ROW0 on: the last block of a row
+// finishes that row), the others a single one.
+enum { TK_HEAD_FWD = 0, TK_HEAD_BWD, TK_ADAM_L2, TK_SINGLES = 16, TK_ROW0 = 16, TK_ROWS = 1024, TK_COUNT = TK_ROW0 + TK_ROWS };
+unsigned* xdfm_ticket(int slot);            // [host] device address of the current device's slot, or nullptr
+#ifdef __HIPCC__
+// A partial another block of the same launch will read: written through to the level all 8 XCDs see (an agent-scope
+// store), so that NO release fence is needed -- on gfx950 an agent-scope release writes back the XCD's whole L2
+// (buffer_wbl2), and one of those per block made the fused dOut pass five times slower.
+__device__ __forceinline__ void xdfm_publish(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ... and read by the last block with ordinary (pipelined) loads after ONE acquire, which xdfm_last_block_done issues for
+// the block that returns true (per-load agent-scope atomics cost a round trip each: 128 in a row tripled a 9-us kernel)
+__device__ __forceinline__ float xdfm_peer(const float* p) { return *p; }
+// true in every thread of the ONE block that finishes last (all threads of every block call it once, at the end, after
+// their xdfm_publish stores).  Order: the published stores are acknowledged (vmcnt 0) before the block draws its ticket.
+__device__ __forceinline__ bool xdfm_last_block_done(unsigned* __restrict__ ticket, unsigned blocks) {
+    __shared__ unsigned xdfm_tk_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        xdfm_tk_last = t == blocks - 1 ? 1u : 0u;
+        if (t == blocks - 1) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the family's next launch
+    }
+    __syncthreads();
+    const bool last = xdfm_tk_last != 0u;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the other blocks' published partials, past this XCD's cache
+    return last;
+}
+#endif
+
 #define XDFM_REQUIRE(cond, ...) \
     do { if (!(cond)) return xdfm_fail(XDFM_ERR_INVALID, __VA_ARGS__); } while (0)
 
@@ -196,8 +232,8 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
 // cin_dout that also leaves the dW kernel's operands (planes, per-split scales) in the dW workspace (cin_x3_bww.hip)
 int x3_bwd_prep_blocks(bool xp_is_x0, int H, int Hp, int m, long N);      // dbias partials per row
 int x3_bwd_prep(const float* A, int H, long N, int D, int act, const float* dHid, int hid0, int hid_rows, const float* dDir,
-                int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut, float* slots, const float* xp,
-                const float* x0, int Hp, int m, float* ws, hipStream_t st);
+                int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut, float* slots, float* dbias,
+                unsigned* ticket, const float* xp, const float* x0, int Hp, int m, float* ws, hipStream_t st);
 
 bool x3_pack_all_usable(int H, int Hp, int m);
 int x3_pack_all(const xdfm_cin_pack_job* jobs, int L, hipStream_t st);

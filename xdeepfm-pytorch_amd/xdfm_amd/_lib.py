@@ -24,6 +24,7 @@ SIGNATURES = {
     "xdfm_set_option": (c_int, [c_char_p, c_int]),
     "xdfm_get_option": (c_int, [c_char_p]),
     "xdfm_graph_node_census": (c_int, [P, P, P, P]),
+    "xdfm_set_ticket_board": (c_int, [P, c_int]),
     "xdfm_embed_gather_fwd": (c_int, [P, c_long, c_int, P, P, P, P, c_int, c_int, P, P, c_int, P, P, P, P, P]),
     "xdfm_embed_scatter_bwd": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P]),
     "xdfm_embed_scatter_bwd_marked": (c_int, [P, c_long, c_int, P, P, c_int, c_int, P, c_int, P, P, c_long, P, c_long,
@@ -135,6 +136,26 @@ def check(rc, what=""):
         if rc == 1:
             raise ValueError("xdfm %s: %s" % (what, msg))
         raise XdfmError("xdfm %s failed (code %d): %s" % (what, rc, msg))
+
+
+_BOARDS = {}
+
+
+def ticket_board(device):
+    """OPT-IN (XDFM_TICKETS=1): register (once per device) the zeroed ticket array that lets the kernels' last block do the
+    work of the separate "finish" launches (include/xdfm.h, xdfm_set_ticket_board).  Measured on MI355X (round 3): the
+    captured step shrinks from 48 to 40 nodes and gets SLOWER, 2.05 against 1.97 ms -- a block that draws a ticket first
+    waits for its own stores, the device-scope atomic is a ~2 us round trip, and the finishing block's acquire invalidates
+    its XCD's L2 under the blocks still running (the fused dOut pass: 44 -> 83 us).  Off by default; the tests run both."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx in _BOARDS or os.environ.get("XDFM_TICKETS", "0") != "1":
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return                                 # never allocate inside a capture; the eager steps before it come here first
+    with torch.cuda.device(idx):
+        board = torch.zeros(2048, dtype=torch.int32, device=device)
+        check(load().xdfm_set_ticket_board(c_void_p(board.data_ptr()), 2048), "set_ticket_board")
+    _BOARDS[idx] = board
 
 
 def set_option(key, value):

@@ -39,6 +39,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _need_cuda(t: torch.Tensor, name: str):
+    if t.is_cuda:
+        _lib.ticket_board(t.device)
     if not t.is_cuda:
         raise RuntimeError(
             "xdfm: %s is on %s -- the xDeepFM hot path only runs on an MI355X through libxdfm_hip.so; "

@@ -1,4 +1,4 @@
-"""torch.optim.Adam whose step is the library's streaming kernel (K7, `xdfm_adam_step`): one launch per 40
+"""torch.optim.Adam whose step is the library's streaming kernel (K7, `xdfm_adam_step`): one launch per 52
 tensors for every fp32 CUDA parameter -- at BASELINE config 2 the embedding / linear tables are 44 M of the 45 M
 parameters, ATen's multi-tensor kernel moves them at 3.2 TB/s, K7 at 5.7 TB/s, and the ~15 small tensors stop
 costing a 47 us latency-bound launch of their own.  State layout (`step`, `exp_avg`, `exp_avg_sq` per
