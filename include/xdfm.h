@@ -35,7 +35,9 @@
  * ABI 7: xdfm_cin_bwd_x_is_folded (a pure query instead of the "last_sym" probe on the product path); the deferred update's
  * constant table holds 4 floats per step (xdfm_adam_clock.consts: 4 * cap) and its replayed steps run the short forms of
  * csrc/adam_math.h (same bits, about half the issue slots); xdfm_adam_selftest; xdfm_cin_bwd_prep +
- * xdfm_cin_level_bwd_w_prepared (dOut, its fp16 planes and the dW kernel's scales in one pass); xdfm_set_ticket_board.
+ * xdfm_cin_level_bwd_w_prepared (dOut, its fp16 planes and the dW kernel's scales in one pass); xdfm_set_ticket_board;
+ * xdfm_cin_attn_pool_bwd_det (K5's parameter gradients without float atomics); xdfm_cin_level_fwd_ex (direct-connect sums
+ * and ReLU sign bits from the forward's epilogue; the direct-connect half of a level is never stored).
  */
 #ifndef XDFM_H
 #define XDFM_H
@@ -173,6 +175,18 @@ int xdfm_cin_fwd_pack(const float* W, int H, int Hp, int m, float* Wf, void* str
 int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const float* bias,
                        int H, int Hp, int m, long N, int act, float* out, void* stream);
 
+/* The forward of a level with what the CIN does with its output fused into the kernel's epilogue (f16x3 / bf16 arithmetic,
+ * D in {4, 8, 16}: xdfm_cin_level_fwd_ex_supported): rows [0, keep_rows) are stored to out [keep_rows][N]; rows >= dir0 are
+ * summed over the embedding axis into res (res[b * ldres + res_off + row - dir0], interaction.py:245-246: the
+ * direct-connect half of a level in sum pooling is never written out), res == NULL: no sums; mask != NULL: bit n & 31 of
+ * mask[row * mask_ld + (n >> 5)] = out[row][n] > 0 for every row (all the backward needs of a ReLU level's output).
+ * At BASELINE config 2 this removes 84 MB of stores, the three xdfm_cin_direct_sum launches and their 84 MB of reads, and
+ * (with the mask given to xdfm_cin_bwd_prep) 134 MB of reads in the backward, per step. */
+int xdfm_cin_level_fwd_ex_supported(int H, int Hp, int m, int D);
+int xdfm_cin_level_fwd_ex(const float* xp, const float* x0, const float* Wf, const float* bias, int H, int Hp, int m, long N,
+                          int act, float* out, int keep_rows, float* res, long ldres, int res_off, int dir0, int D,
+                          unsigned* mask, long mask_ld, void* stream);
+
 /* sum over the embedding axis of `rows` feature maps (interaction.py:245-246):
  * res[b*ldres + off + r] = sum_d A[(row0 + r)][b*D + d] */
 int xdfm_cin_direct_sum(const float* A, int row0, int rows, int B, int D,
@@ -233,11 +247,14 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
  * slab.  *prepared [host] = 1 when that happened: the caller then calls xdfm_cin_level_bwd_w_prepared with the same xp,
  * x0, shapes, workspace and options; 0 when the shape has no f16x3 / bf16 dW kernel (H <= 64, D % 4 != 0, unaligned
  * rows, cin_math 0): the call then was xdfm_cin_dout_det and xdfm_cin_level_bwd_w does its own passes.
- * dout_ws: xdfm_cin_bwd_prep_ws_elems floats (dbias partials, added up in a fixed order).  dbias is added to. */
+ * dout_ws: xdfm_cin_bwd_prep_ws_elems floats (dbias partials, added up in a fixed order).  dbias is added to.
+ * mask != NULL: the ReLU mask comes from the sign bits xdfm_cin_level_fwd_ex left (bit n & 31 of mask[h * mask_ld + (n >> 5)]
+ * = out[h][n] > 0) and A is not read (may be NULL): the level's output then need not be kept at all beyond its hidden
+ * rows, which travel as xp. */
 size_t xdfm_cin_bwd_prep_ws_elems(int H, int Hp, int m, int B, int D);
-int xdfm_cin_bwd_prep(const float* A, int H, int B, int D, int act, const float* dHid, int hid0, int hid_rows,
-                      const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut,
-                      float* dbias, float* dout_ws, const float* xp, const float* x0, int Hp, int m, float* bww_ws,
+int xdfm_cin_bwd_prep(const float* A, const unsigned* mask, long mask_ld, int H, int B, int D, int act, const float* dHid,
+                      int hid0, int hid_rows, const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+                      float* dOut, float* dbias, float* dout_ws, const float* xp, const float* x0, int Hp, int m, float* bww_ws,
                       int* prepared, void* stream);
 int xdfm_cin_level_bwd_w_prepared(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,
                                   float* ws, float* dW, void* stream);
@@ -273,6 +290,14 @@ int xdfm_cin_attn_pool_bwd(const float* fm, int B, int S, int D, int nh, int n_l
                            const float* theta, const float* tok_save, const float* o_save, const float* ml_save,
                            const float* dout, float* dfm, float* dtheta, float p_drop,
                            const unsigned long long* drop_seed, void* stream);
+/* Same without float atomics: every workgroup stores its share of the parameter gradients in `ws`
+ * (xdfm_cin_attn_pool_bwd_ws_elems floats) and a second small launch adds the shares in workgroup order -- dtheta is
+ * OVERWRITTEN (no zero-fill) and has the same bits on every run. */
+size_t xdfm_cin_attn_pool_bwd_ws_elems(int B, int D, int n_layers, int use_ln);
+int xdfm_cin_attn_pool_bwd_det(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
+                               const float* theta, const float* tok_save, const float* o_save, const float* ml_save,
+                               const float* dout, float* dfm, float* dtheta, float* ws, float p_drop,
+                               const unsigned long long* drop_seed, void* stream);
 /* keep[n_layers][B][nh][S(query)][S(key)] (1 = kept): the mask the two calls above generate for this seed.
  * Test hook: lets a CPU oracle apply the same mask where the reference applies nn.Dropout. */
 int xdfm_cin_attn_dropout_mask(int B, int S, int nh, int n_layers, float p_drop, const unsigned long long* drop_seed,

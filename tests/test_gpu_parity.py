@@ -881,14 +881,54 @@ def test_full_size_cin_rows_vs_oracle_subset(cin_math):
         gclose(c.bias.grad, Bs[i].grad.numpy(), "db%d" % i)
 
 
+@pytest.mark.parametrize("cls_name,B,D,kw", [
+    ("xDeepFMAttention", 512, 16, dict(cin_num_heads=4)),
+    ("xDeepFMAttentionV2", 300, 8, dict(cin_num_heads=2, cin_num_attn_layers=2)),
+    ("xDeepFMAttention", 96, 16, dict(cin_num_heads=4, cin_attn_dropout=0.2)),
+], ids=["attn", "attn_v2_two_layers", "attn_dropout"])
+def test_attention_step_gradients_are_bit_identical_run_to_run(cls_name, B, D, kw):
+    """K5 (attention block): since round 3 its parameter gradients are per-workgroup shares added in workgroup order
+    (xdfm_cin_attn_pool_bwd_det) and the block sums inside a workgroup go through LDS in wave order -- no float atomics.
+    Forward + backward four times on one batch: prediction and every gradient (incl. W_q / W_k / W_v / W_o, LayerNorm
+    and pooling parameters) must have the same bits each time; with dropout the seed is fixed per repetition."""
+    from deepctr.inputs import DenseFeat, SparseFeat
+    from deepctr import models
+    from oracle import xdeepfm_oracle as orc
+    dev = _dev()
+    vocab = [400] * 26
+    cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)] + [DenseFeat("I%d" % (i + 1), 1) for i in range(13)]
+    torch.manual_seed(9)
+    model = getattr(models, cls_name)(cols, cols, cin_layer_size=(64, 48), l2_reg_dnn=1e-5, device=dev, **kw)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if "embedding_dict" in k:
+                p.mul_(3000.0)
+    model.train()
+    X, y = orc.synthetic_batch(B, vocab, 13, seed=12)
+    X, y = T(X).to(dev), T(y).to(dev)
+    ref = None
+    for rep in range(4):
+        torch.manual_seed(77)                    # the dropout seed is drawn from torch's generator
+        model.zero_grad()
+        out = model(X)
+        torch.nn.functional.binary_cross_entropy(out.squeeze(), y.squeeze(), reduction="sum").backward()
+        got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        got["prediction"] = out.detach().clone()
+        if ref is None:
+            ref = got
+            assert any("mhsa" in k for k in ref) and any("attn_pooling" in k for k in ref)
+        else:
+            for k in ref:
+                assert torch.equal(got[k], ref[k]), "run %d: %s differs" % (rep, k)
+
+
 @pytest.mark.parametrize("B,D", [(4096, 16), (256, 10)])
 def test_whole_step_gradients_are_bit_identical_run_to_run(B, D, cin_math):
     """Forward + backward of the xDeepFM step five times on one batch: the prediction and EVERY parameter gradient must
     be the same bits each time, at BASELINE config 2's size and at the scripts' default embedding_dim = 10 (generic,
     non-vectorised code paths).  What this pins: K2 is an exact reduce, dW sums its slabs in a fixed order, and the CIN
     bias gradients are per-block partials added in block order (they were one float atomic per block: 16 blocks per row
-    at B = 4096 -- found by the deferred-Adam bit-equality test).  The attention variants are not covered: K5's parameter
-    gradients are accumulated with float atomics (include/xdfm.h)."""
+    at B = 4096 -- found by the deferred-Adam bit-equality test).  The attention variants have their own test above."""
     from deepctr.inputs import DenseFeat, SparseFeat
     from deepctr.models import xDeepFM
     from oracle import xdeepfm_oracle as orc

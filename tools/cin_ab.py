@@ -24,7 +24,10 @@ ref = None
 for rep in range(2):
     for cfg in configs:
         for k, v in cfg.items():
-            _lib.set_option(k, v)
+            if k == "lean":                      # pseudo-option: the forward's fused direct sums / sign bits (ops.CINStack)
+                os.environ["XDFM_CIN_LEAN"] = str(v)
+            else:
+                _lib.set_option(k, v)
         for _ in range(3):
             layer.zero_grad(); x.grad = None
             y = layer(x); y.sum().backward()

@@ -452,14 +452,24 @@ __device__ __forceinline__ void outer_accumulate(float* __restrict__ dst, const 
     }
 }
 
-// dst[d] += sum over the block of v[d] (wave shuffles, then one LDS atomic per wave and element)
+// dst[d] += sum over the block of v[d]: wave shuffles, the waves' sums parked in LDS (scratch: 16 * D floats) and added in
+// wave order by one thread per element -- no float atomics, the same bits on every run (an LDS atomic per wave and
+// element, as before round 3, added the waves in whatever order they arrived).  Every thread of the block calls it.
 template <int D>
-__device__ __forceinline__ void vec_accumulate(float* __restrict__ dst, const float (&v)[D]) {
+__device__ __forceinline__ void vec_accumulate(float* __restrict__ dst, const float (&v)[D], float* __restrict__ scratch) {
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const float t = wave_sum(v[d]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&dst[d], t);
+        if ((threadIdx.x & 63) == 0) scratch[w * D + d] = t;
     }
+    __syncthreads();
+    if ((int)threadIdx.x < D) {
+        float s = 0.f;
+        for (int k = 0; k < nw; ++k) s += scratch[k * D + threadIdx.x];
+        dst[threadIdx.x] += s;
+    }
+    __syncthreads();
 }
 
 // LDS carve-up of the backward kernel (floats).  TP = rows of the per-thread tiles = blockDim.
@@ -484,7 +494,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
     const float* __restrict__ fm, long N, int B, int S, int n_layers, int use_ln, int use_res,
     const float* __restrict__ theta, const float* __restrict__ tok_save, const float* __restrict__ o_save,
     const float* __restrict__ ml_save, const float* __restrict__ dout, float* __restrict__ dfm,
-    float* __restrict__ dtheta, AttnDrop drop) {
+    float* __restrict__ dtheta, float* __restrict__ part, AttnDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int HD = D / NH;
     constexpr int XP = D + 1;
@@ -546,8 +556,8 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                 du[i] = de * WN[D * D + D + i] * (1.f - th[i] * th[i]);      // through tanh
                 zrow[i] = du[i];
             }
-            vec_accumulate<D>(accp + D * D + D, g2);
-            vec_accumulate<D>(accp + D * D, du);
+            vec_accumulate<D>(accp + D * D + D, g2, red + 16);
+            vec_accumulate<D>(accp + D * D, du, red + 16);
 #pragma unroll
             for (int d = 0; d < D; ++d) da[d] = alpha * dpool[d];
             matvec_acc<D>(WN, zrow, da);                 // += W1^T du
@@ -627,8 +637,8 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                     m2 *= (1.0f / D);
 #pragma unroll
                     for (int d = 0; d < D; ++d) dy[d] = rstd * (da[d] * g[d] - m1 - yh[d] * m2);
-                    vec_accumulate<D>(accl + 4 * D * D, dg);          // dgamma
-                    vec_accumulate<D>(accl + 4 * D * D + D, da);      // dbeta
+                    vec_accumulate<D>(accl + 4 * D * D, dg, red + 16);          // dgamma
+                    vec_accumulate<D>(accl + 4 * D * D + D, da, red + 16);      // dbeta
                 } else {
 #pragma unroll
                     for (int d = 0; d < D; ++d) dy[d] = da[d];
@@ -753,26 +763,53 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < asz; i += blockDim.x) atomicAdd(&dtheta[i], Acc[i]);
+    // the workgroup's share of the parameter gradients: its own row of `part`, summed over the workgroups in a fixed order
+    // by attn_dtheta_finish_kernel -- or (no workspace: the round-2 entry point) fp32 atomics, whose order varies
+    if (part) { for (int i = threadIdx.x; i < asz; i += blockDim.x) part[(long)blockIdx.x * asz + i] = Acc[i]; }
+    else { for (int i = threadIdx.x; i < asz; i += blockDim.x) atomicAdd(&dtheta[i], Acc[i]); }
 }
+
+// dtheta[i] = sum over the workgroups of part[g][i], in workgroup order: 8 loads in flight, one add chain
+__global__ __launch_bounds__(256) void attn_dtheta_finish_kernel(const float* __restrict__ part, int asz, int groups,
+                                                                 float* __restrict__ dtheta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= asz) return;
+    float s = 0.f;
+    int g = 0;
+    for (; g + 8 <= groups; g += 8) {
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = part[(long)(g + q) * asz + i];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += t[q];
+    }
+    for (; g < groups; ++g) s += part[(long)g * asz + i];
+    dtheta[i] = s;
+}
+
+static inline int attn_bwd_groups(int B) { return B < 2048 ? B : 2048; }       // workgroups of the backward launch
 
 template <int D, int NH>
 static int launch_attn_bwd(const float* fm, int B, int S, int n_layers, int use_ln, int use_res, const float* theta,
                            const float* tok_save, const float* o_save, const float* ml_save, const float* dout,
-                           float* dfm, float* dtheta, AttnDrop drop, hipStream_t st) {
+                           float* dfm, float* dtheta, float* part, AttnDrop drop, hipStream_t st) {
     const int threads = (int)round_up(S, 64);
     const size_t lds = (size_t)attn_bwd_layout(S, D, NH, n_layers, threads).total * sizeof(float);
     if (lds > 160 * 1024) return xdfm_fail(XDFM_ERR_INVALID, "cin_attn_pool_bwd: S=%d D=%d does not fit LDS", S, D);
-    const int grid = B < 2048 ? B : 2048;
+    const int grid = attn_bwd_groups(B);
 #define XDFM_ATTN_BWD(TB, DR)                                                                                          \
     hipLaunchKernelGGL((attn_pool_bwd_kernel<D, NH, TB, DR>), dim3(grid), dim3(threads), lds, st, fm, (long)B * D, B, S, \
-                       n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta, drop)
+                       n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta, part, drop)
     if (drop.seed) {
         if (threads <= 512) XDFM_ATTN_BWD(512, true); else XDFM_ATTN_BWD(1024, true);
     } else {
         if (threads <= 512) XDFM_ATTN_BWD(512, false); else XDFM_ATTN_BWD(1024, false);
     }
 #undef XDFM_ATTN_BWD
+    if (part) {
+        const int asz = n_layers * (4 * D * D + (use_ln ? 2 * D : 0)) + D * D + 2 * D;
+        hipLaunchKernelGGL(attn_dtheta_finish_kernel, dim3(ceil_div(asz, 256)), dim3(256), 0, st, part, asz, grid, dtheta);
+    }
     return xdfm_check_launch("cin_attn_pool_bwd");
 }
 
@@ -833,7 +870,27 @@ int xdfm_cin_attn_pool_bwd(const float* fm, int B, int S, int D, int nh, int n_l
     if (int rc = attn_drop_args(p_drop, drop_seed, &drop, "cin_attn_pool_bwd")) return rc;
     hipStream_t st = (hipStream_t)stream;
     ATTN_DISPATCH(launch_attn_bwd, fm, B, S, n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta,
-                  drop, st)
+                  (float*)nullptr, drop, st)
+}
+
+size_t xdfm_cin_attn_pool_bwd_ws_elems(int B, int D, int n_layers, int use_ln) {
+    if (B <= 0 || D <= 0 || n_layers <= 0) return 0;
+    return (size_t)attn_bwd_groups(B) * xdfm_cin_attn_theta_elems(D, n_layers, use_ln);
+}
+
+int xdfm_cin_attn_pool_bwd_det(const float* fm, int B, int S, int D, int nh, int n_layers, int use_ln, int use_res,
+                               const float* theta, const float* tok_save, const float* o_save, const float* ml_save,
+                               const float* dout, float* dfm, float* dtheta, float* ws, float p_drop,
+                               const unsigned long long* drop_seed, void* stream) {
+    XDFM_REQUIRE(fm && theta && tok_save && o_save && ml_save && dout && dfm && dtheta && ws,
+                 "cin_attn_pool_bwd: null pointer");
+    XDFM_REQUIRE(B > 0 && S > 0 && S <= 1024 && n_layers >= 1, "cin_attn_pool_bwd: bad shape B=%d S=%d layers=%d", B, S,
+                 n_layers);
+    AttnDrop drop;
+    if (int rc = attn_drop_args(p_drop, drop_seed, &drop, "cin_attn_pool_bwd")) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    ATTN_DISPATCH(launch_attn_bwd, fm, B, S, n_layers, use_ln, use_res, theta, tok_save, o_save, ml_save, dout, dfm, dtheta,
+                  ws, drop, st)
 }
 
 int xdfm_cin_attn_dropout_mask(int B, int S, int nh, int n_layers, float p_drop, const unsigned long long* drop_seed,

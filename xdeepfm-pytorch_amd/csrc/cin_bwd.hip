@@ -20,11 +20,13 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
     const float* __restrict__ A, int H, long N, int D, int act,
     const float* __restrict__ dHid, int hid0, int hid_rows,
     const float* __restrict__ dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
-    float* __restrict__ dOut, float* __restrict__ dbias, float* __restrict__ slots, unsigned* __restrict__ ticket) {
+    float* __restrict__ dOut, float* __restrict__ dbias, float* __restrict__ slots, unsigned* __restrict__ ticket,
+    const unsigned* __restrict__ mask, long mask_ld) {
     const int h = blockIdx.y;
     const bool has_hid = dHid && h >= hid0 && h < hid0 + hid_rows;
     const bool has_dir = dDir && h >= dir0 && h < dir0 + dir_rows;
-    const float* __restrict__ arow = A + (long)h * N;
+    const float* __restrict__ arow = mask ? dOut : A + (long)h * N;        // with sign bits (X3FwdEpi.mask) the saved output is not read
+    const unsigned* __restrict__ mrow = mask ? mask + (long)h * mask_ld : nullptr;
     const float* __restrict__ hrow = has_hid ? dHid + (long)(h - hid0) * N : nullptr;
     const float* __restrict__ drow = (has_dir && dir_mode == 1) ? dDir + (long)(dir_off + h - dir0) * N : nullptr;
     const float* __restrict__ dres = (has_dir && dir_mode == 0) ? dDir + dir_off + (h - dir0) : nullptr;
@@ -37,8 +39,13 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
         if (n < N) {
             float g[VEC], a[VEC];
             if constexpr (VEC == 4) {
-                const float4 av = *reinterpret_cast<const float4*>(arow + n);
-                a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+                if (mrow) {
+                    const unsigned w = mrow[n >> 5] >> (n & 31);
+                    a[0] = (w & 1u) ? 1.f : 0.f; a[1] = (w & 2u) ? 1.f : 0.f; a[2] = (w & 4u) ? 1.f : 0.f; a[3] = (w & 8u) ? 1.f : 0.f;
+                } else {
+                    const float4 av = *reinterpret_cast<const float4*>(arow + n);
+                    a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+                }
                 g[0] = g[1] = g[2] = g[3] = 0.f;
                 if (hrow) {
                     const float4 hv = *reinterpret_cast<const float4*>(hrow + n);
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
                     g[0] += r; g[1] += r; g[2] += r; g[3] += r;
                 }
             } else {
-                a[0] = arow[n];
+                a[0] = mrow ? (((mrow[n >> 5] >> (n & 31)) & 1u) ? 1.f : 0.f) : arow[n];
                 g[0] = hrow ? hrow[n] : 0.f;
                 if (drow) g[0] += drow[n];
                 if (dres) g[0] += dres[(n / D) * lddir];
@@ -762,10 +769,21 @@ int xdfm_cin_dout(const float* A, int H, int B, int D, int act, const float* dHi
                              nullptr, stream);
 }
 
+static int cin_dout_impl(const float* A, const unsigned* mask, long mask_ld, int H, int B, int D, int act, const float* dHid,
+                         int hid0, int hid_rows, const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+                         float* dOut, float* dbias, float* ws, void* stream);
+
 int xdfm_cin_dout_det(const float* A, int H, int B, int D, int act, const float* dHid, int hid0, int hid_rows,
                       const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
                       float* dOut, float* dbias, float* ws, void* stream) {
-    XDFM_REQUIRE(A && dOut && dbias, "cin_dout: null pointer");
+    return cin_dout_impl(A, nullptr, 0, H, B, D, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir, dir_off, dir0, dir_rows, dOut,
+                         dbias, ws, stream);
+}
+
+static int cin_dout_impl(const float* A, const unsigned* mask, long mask_ld, int H, int B, int D, int act, const float* dHid,
+                         int hid0, int hid_rows, const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+                         float* dOut, float* dbias, float* ws, void* stream) {
+    XDFM_REQUIRE((A || mask) && dOut && dbias, "cin_dout: null pointer");
     XDFM_REQUIRE(H > 0 && B > 0 && D > 0, "cin_dout: bad shape H=%d B=%d D=%d", H, B, D);
     XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_dout: unsupported activation %d", act);
     XDFM_REQUIRE(hid_rows >= 0 && dir_rows >= 0 && hid0 >= 0 && dir0 >= 0 && hid0 + hid_rows <= H &&
@@ -774,15 +792,15 @@ int xdfm_cin_dout_det(const float* A, int H, int B, int D, int act, const float*
     const long N = (long)B * D;
     const float* dh = hid_rows > 0 ? dHid : nullptr;
     const float* dd = dir_rows > 0 ? dDir : nullptr;
-    const bool vec = cin_dout_vec(A, N, D, dOut, dh, dd);
+    const bool vec = cin_dout_vec(mask ? dOut : A, N, D, dOut, dh, dd);
     const int gx = ceil_div(N, vec ? 4096 : 1024);
     unsigned* ticket = (ws && H <= TK_ROWS) ? xdfm_ticket(TK_ROW0) : nullptr;
     if (vec)
         hipLaunchKernelGGL(cin_dout_kernel<4>, dim3(gx, H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
-                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws, ticket);
+                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws, ticket, mask, mask_ld);
     else
         hipLaunchKernelGGL(cin_dout_kernel<1>, dim3(gx, H), dim3(256), 0, (hipStream_t)stream, A, H, N, D,
-                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws, ticket);
+                           act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias, ws, ticket, mask, mask_ld);
     if (ws && !ticket) hipLaunchKernelGGL(cin_dbias_finish_kernel, dim3(ceil_div(H, 64)), dim3(64), 0, (hipStream_t)stream, ws, H, gx, dbias);
     return xdfm_check_launch("cin_dout");
 }
@@ -878,20 +896,21 @@ size_t xdfm_cin_bwd_prep_ws_elems(int H, int Hp, int m, int B, int D) {
     return n;
 }
 
-int xdfm_cin_bwd_prep(const float* A, int H, int B, int D, int act, const float* dHid, int hid0, int hid_rows,
-                      const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut,
-                      float* dbias, float* dout_ws, const float* xp, const float* x0, int Hp, int m, float* bww_ws,
+int xdfm_cin_bwd_prep(const float* A, const unsigned* mask, long mask_ld, int H, int B, int D, int act, const float* dHid,
+                      int hid0, int hid_rows, const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
+                      float* dOut, float* dbias, float* dout_ws, const float* xp, const float* x0, int Hp, int m, float* bww_ws,
                       int* prepared, void* stream) {
     XDFM_REQUIRE(prepared, "cin_bwd_prep: null pointer");
+    XDFM_REQUIRE(!mask || mask_ld >= ((long)B * D + 31) / 32, "cin_bwd_prep: mask pitch %ld", mask_ld);
     *prepared = 0;
     const long N = (long)B * D;
     const float* dh = hid_rows > 0 ? dHid : nullptr;
     const float* dd = dir_rows > 0 ? dDir : nullptr;
-    const bool fused = dout_ws && bww_ws && xp && x0 && Hp > 0 && m > 0 && H > 0 && B > 0 && D > 0 && A && dOut &&
-                       x3_bww_usable(dOut, xp, x0, H, N) && cin_dout_vec(A, N, D, dOut, dh, dir_mode == 1 ? dd : nullptr);
+    const bool fused = dout_ws && bww_ws && xp && x0 && Hp > 0 && m > 0 && H > 0 && B > 0 && D > 0 && (A || mask) && dOut &&
+                       x3_bww_usable(dOut, xp, x0, H, N) && cin_dout_vec(mask ? dOut : A, N, D, dOut, dh, dir_mode == 1 ? dd : nullptr);
     if (!fused)
-        return xdfm_cin_dout_det(A, H, B, D, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dbias,
-                                 dout_ws, stream);
+        return cin_dout_impl(A, mask, mask_ld, H, B, D, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir, dir_off, dir0, dir_rows, dOut,
+                             dbias, dout_ws, stream);
     XDFM_REQUIRE(dbias, "cin_bwd_prep: null pointer");
     XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_bwd_prep: unsupported activation %d", act);
     XDFM_REQUIRE(hid_rows >= 0 && dir_rows >= 0 && hid0 >= 0 && dir0 >= 0 && hid0 + hid_rows <= H && dir0 + dir_rows <= H,
@@ -899,7 +918,7 @@ int xdfm_cin_bwd_prep(const float* A, int H, int B, int D, int act, const float*
     XDFM_REQUIRE(dir_mode == 0 || dir_mode == 1, "cin_bwd_prep: dir_mode %d", dir_mode);
     hipStream_t st = (hipStream_t)stream;
     unsigned* ticket = H <= TK_ROWS ? xdfm_ticket(TK_ROW0) : nullptr;
-    int rc = x3_bwd_prep(A, H, N, D, act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dout_ws, dbias,
+    int rc = x3_bwd_prep(A, mask, mask_ld, H, N, D, act, dh, hid0, hid_rows, dd, dir_mode, lddir, dir_off, dir0, dir_rows, dOut, dout_ws, dbias,
                          ticket, xp, x0, Hp, m, bww_ws, st);
     if (rc) return rc;
     if (!ticket)

@@ -455,7 +455,7 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_fwd: bad shape H=%d Hp=%d m=%d N=%ld", H, Hp, m, N);
     XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_level_fwd: unsupported activation %d", act);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_fwd_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_FWD, xdfm_opt(OPT_CIN_MATH)); return x3_level_fwd(xp, x0, Wf, bias, H, Hp, m, N, act, out, st); }
+    if (x3_fwd_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_FWD, xdfm_opt(OPT_CIN_MATH)); return x3_level_fwd(xp, x0, Wf, bias, H, Hp, m, N, act, out, x3_fwd_epi_plain(H), st); }
     xdfm_opt_note(OPT_LAST_FWD, 0);
     xdfm_opt_note(OPT_LAST_SYM, xdfm_opt(OPT_LAST_SYM) & ~1);
     const int nf = xdfm_opt(OPT_FWD_NF) == 2 ? 2 : 1;
@@ -467,6 +467,29 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
                            : launch_fwd<4, 1>(xp, x0, Wf, bias, H, Hp, m, N, act, out, st);
         default: return launch_fwd<8, 1>(xp, x0, Wf, bias, H, Hp, m, N, act, out, st);
     }
+}
+
+int xdfm_cin_level_fwd_ex_supported(int H, int Hp, int m, int D) {
+    return (H > 0 && Hp > 0 && m > 0 && (D == 4 || D == 8 || D == 16) && x3_fwd_usable(H, Hp, m)) ? 1 : 0;
+}
+
+int xdfm_cin_level_fwd_ex(const float* xp, const float* x0, const float* Wf, const float* bias, int H, int Hp, int m, long N,
+                          int act, float* out, int keep_rows, float* res, long ldres, int res_off, int dir0, int D,
+                          unsigned* mask, long mask_ld, void* stream) {
+    XDFM_REQUIRE(xp && x0 && Wf && bias, "cin_level_fwd_ex: null pointer");
+    XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_fwd_ex: bad shape H=%d Hp=%d m=%d N=%ld", H, Hp, m, N);
+    XDFM_REQUIRE(act == XDFM_ACT_LINEAR || act == XDFM_ACT_RELU, "cin_level_fwd_ex: unsupported activation %d", act);
+    XDFM_REQUIRE(xdfm_cin_level_fwd_ex_supported(H, Hp, m, D), "cin_level_fwd_ex: no f16x3 / bf16 forward kernel with this epilogue "
+                 "for H=%d Hp=%d m=%d D=%d (xdfm_cin_level_fwd_ex_supported)", H, Hp, m, D);
+    XDFM_REQUIRE(keep_rows >= 0 && keep_rows <= H && (keep_rows == 0 || out), "cin_level_fwd_ex: keep_rows %d of %d", keep_rows, H);
+    XDFM_REQUIRE(!res || (dir0 >= 0 && dir0 <= H && ldres >= res_off + (H - dir0) && res_off >= 0 && N % D == 0),
+                 "cin_level_fwd_ex: bad direct-sum arguments");
+    XDFM_REQUIRE(!mask || mask_ld >= (N + 31) / 32, "cin_level_fwd_ex: mask pitch %ld", mask_ld);
+    int logD = 0;
+    while ((1 << logD) < D) ++logD;
+    const X3FwdEpi epi = {keep_rows, res, ldres, res_off, res ? dir0 : H, logD, mask, mask_ld};
+    xdfm_opt_note(OPT_LAST_FWD, xdfm_opt(OPT_CIN_MATH));
+    return x3_level_fwd(xp, x0, Wf, bias, H, Hp, m, N, act, out, epi, (hipStream_t)stream);
 }
 
 int xdfm_cin_direct_sum(const float* A, int row0, int rows, int B, int D, float* res, long ldres, int off,

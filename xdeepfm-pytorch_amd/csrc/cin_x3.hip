@@ -236,7 +236,7 @@ int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
 }
 
 int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
-                 int act, float* out, hipStream_t st) {
+                 int act, float* out, const X3FwdEpi& epi, hipStream_t st) {
     const X3Geom g = x3_fwd_geom(H, Hp, m);
     const int nt = x3_terms();
     act |= ((xdfm_opt(OPT_DBG) >> 6) & 255) << 8;     // timing experiments (results become wrong): see the kernels' `dbg`
@@ -245,11 +245,11 @@ int x3_level_fwd(const float* xp, const float* x0, const float* pack, const floa
     const bool sym = xp == x0 && x3_fwd_has_sym(Hp, m) && xdfm_opt(OPT_X3_SYM) != 0;
     xdfm_opt_note(OPT_LAST_SYM, (xdfm_opt(OPT_LAST_SYM) & ~1) | (sym ? 1 : 0));
     if (sym)
-        return x3_level_fwd_sym(x0, pack + x3_fwd_sym_offset(H, Hp, m), bias, H, m, N, x3_fwd_geom_sym(H, m), nt, act, out, st);
+        return x3_level_fwd_sym(x0, pack + x3_fwd_sym_offset(H, Hp, m), bias, H, m, N, x3_fwd_geom_sym(H, m), nt, act, out, epi, st);
     if (m == 26) return X3_FWD_DISPATCH_M(26);
     if (m == 22) return X3_FWD_DISPATCH_M(22);
-    if (m < 22) return x3_level_fwd_ma(xp, x0, pack, bias, H, Hp, m, N, g, nt, act, out, st);
-    if (m <= 40) return x3_level_fwd_mb(xp, x0, pack, bias, H, Hp, m, N, g, nt, act, out, st);
+    if (m < 22) return x3_level_fwd_ma(xp, x0, pack, bias, H, Hp, m, N, g, nt, act, out, epi, st);
+    if (m <= 40) return x3_level_fwd_mb(xp, x0, pack, bias, H, Hp, m, N, g, nt, act, out, epi, st);
     return xdfm_fail(XDFM_ERR_INVALID, "cin_level_fwd (f16x3 / bf16): no kernel for MT=%d m=%d terms=%d", g.MT, m, nt);
 }
 

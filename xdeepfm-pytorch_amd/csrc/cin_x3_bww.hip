@@ -581,7 +581,7 @@ __device__ __forceinline__ int x3_div(unsigned n, X3Magic k) { return (int)(((un
 
 template <int NT>
 __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
-    const float* __restrict__ A, int H, long N, X3Magic divD, int act,
+    const float* __restrict__ A, const unsigned* __restrict__ mask, long mask_ld, int H, long N, X3Magic divD, int act,
     const float* __restrict__ dHid, int hid0, int hid_rows,
     const float* __restrict__ dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
     float* __restrict__ dOut, float* __restrict__ slots, float* __restrict__ dbias, unsigned* __restrict__ ticket,
@@ -603,7 +603,11 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
     const bool is_d = y < Hpad, is_xp = !is_d && y < Hpad + IPAD;
     const int row = is_d ? y : (is_xp ? y - Hpad : y - Hpad - IPAD);
     const bool real = is_d ? row < H : (is_xp ? row < Hp : true);
-    const float* __restrict__ src = (is_d ? A + (long)(real ? row : 0) * N : (is_xp ? xp + (long)(real ? row : 0) * N : x0 + (long)row * N)) + c0;
+    // the ReLU mask of a dOut row: the sign bits the forward left (X3FwdEpi.mask), or the saved output itself
+    const bool use_mask = is_d && mask != nullptr;
+    const unsigned* __restrict__ mrow = use_mask ? mask + (long)(real ? row : 0) * mask_ld : nullptr;
+    const float* __restrict__ src = (is_d ? (use_mask ? dOut : A + (long)(real ? row : 0) * N)
+                                          : (is_xp ? xp + (long)(real ? row : 0) * N : x0 + (long)row * N)) + c0;
     const bool has_hid = is_d && real && dHid && row >= hid0 && row < hid0 + hid_rows;
     const bool has_dir = is_d && real && dDir && row >= dir0 && row < dir0 + dir_rows;
     const float* __restrict__ hrow = has_hid ? dHid + (long)(row - hid0) * N + c0 : nullptr;
@@ -611,8 +615,12 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
     const float* __restrict__ dres = (has_dir && dir_mode == 0) ? dDir + dir_off + (row - dir0) : nullptr;
     float* __restrict__ orow = dOut + (long)(is_d && real ? row : 0) * N + c0;
     // the values of 4 columns at offset o (o % 4 == 0, o < nreal): dOut for a dOut row, the operand itself for x_prev / x0
+    auto keep4 = [&](int o) -> float4 {                  // 1.0 where the level's output was > 0 (4 columns at offset o)
+        const unsigned w = mrow[(c0 + o) >> 5] >> ((c0 + o) & 31);
+        return make_float4((w & 1u) ? 1.f : 0.f, (w & 2u) ? 1.f : 0.f, (w & 4u) ? 1.f : 0.f, (w & 8u) ? 1.f : 0.f);
+    };
     auto value = [&](int o) -> float4 {
-        const float4 av = *reinterpret_cast<const float4*>(src + o);
+        const float4 av = use_mask ? keep4(o) : *reinterpret_cast<const float4*>(src + o);
         if (!is_d) return av;
         float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hrow) g = *reinterpret_cast<const float4*>(hrow + o);
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
                     const bool ok = it < iters && o[it] + 4 * q < nreal;
                     oc[it][q] = ok ? o[it] + 4 * q : 0;
                     msk[it][q] = ok ? 1.f : 0.f;
-                    av[it][q] = *reinterpret_cast<const float4*>(src + oc[it][q]);
+                    av[it][q] = use_mask ? keep4(oc[it][q]) : *reinterpret_cast<const float4*>(src + oc[it][q]);
                     g[it][q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -817,7 +825,7 @@ int x3_bwd_prep_blocks(bool xp_is_x0, int H, int Hp, int m, long N) {
     return ceil_div(g.nsplit, KS);
 }
 
-int x3_bwd_prep(const float* A, int H, long N, int D, int act, const float* dHid, int hid0, int hid_rows, const float* dDir,
+int x3_bwd_prep(const float* A, const unsigned* mask, long mask_ld, int H, long N, int D, int act, const float* dHid, int hid0, int hid_rows, const float* dDir,
                 int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut, float* slots, float* dbias,
                 unsigned* ticket, const float* xp, const float* x0, int Hp, int m, float* ws, hipStream_t st) {
     const int NW = x3_bww_waves();
@@ -833,11 +841,11 @@ int x3_bwd_prep(const float* A, int H, long N, int D, int act, const float* dHid
     XDFM_REQUIRE(N < (1L << 31) && g.n_per_split < (1L << 30), "cin_bwd_prep: N = %ld columns", N);
     const X3Magic divD = x3_magic(D), divS = x3_magic(g.n_per_split);
     if (x3_terms() == 3)
-        hipLaunchKernelGGL(x3_bwd_prep_kernel<3>, grid, dim3(256), 0, st, A, H, N, divD, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir,
+        hipLaunchKernelGGL(x3_bwd_prep_kernel<3>, grid, dim3(256), 0, st, A, mask, mask_ld, H, N, divD, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir,
                            dir_off, dir0, dir_rows, dOut, slots, dbias, ticket, xp, x0, Hp, m, g.Hpad, g.IPAD, (int)g.n_per_split, divS, KS, g.nsplit, hdr2,
                            w.HS, planes, w.NP);
     else
-        hipLaunchKernelGGL(x3_bwd_prep_kernel<1>, grid, dim3(256), 0, st, A, H, N, divD, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir,
+        hipLaunchKernelGGL(x3_bwd_prep_kernel<1>, grid, dim3(256), 0, st, A, mask, mask_ld, H, N, divD, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir,
                            dir_off, dir0, dir_rows, dOut, slots, dbias, ticket, xp, x0, Hp, m, g.Hpad, g.IPAD, (int)g.n_per_split, divS, KS, g.nsplit, hdr2,
                            w.HS, planes, w.NP);
     return xdfm_check_launch("cin_bwd_prep (f16x3 / bf16)");

@@ -102,7 +102,7 @@ __device__ constexpr X3SymTab<M> x3_symtab{};
 template <int MT, int M, int NW, int R = X3_RING, int NT = 3, int EXP = 0, bool SYM = false>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     const float* __restrict__ xp, const float* __restrict__ x0, const float* __restrict__ pack,
-    const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out) {
+    const float* __restrict__ bias, int H, int Hp, long N, X3Geom G, int act, float* __restrict__ out, X3FwdEpi E) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int MP = M / 2;
     constexpr int FRT = NT == 3 ? 2 : 1;        // 1-KB fragments per row tile (hi, lo | bf16)
@@ -376,16 +376,80 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
     // The bias values of the workgroup's rows sit in LDS since the prologue: their reads count on lgkmcnt, so nothing
     // makes hipcc put an s_waitcnt vmcnt(0) -- which also waits for the previous STORE -- in front of every store
     // (with per-row global loads of the bias it did: 16 write round trips per row tile).
+    // X3FwdEpi (xdfm_internal.h): rows >= keep_rows are not stored; rows >= dir0 are summed over the embedding axis into
+    // `res`; the ReLU sign bits of every row go to `mask`.
     const float sc = NT == 3 ? pack[1] * (1.f / sp) * (1.f / s0) : 1.f;
+    const long wcol = ((long)blockIdx.x * NW + wave) * 32;       // first column of this wave
+    const int Dm1 = (1 << E.logD) - 1;
+    const bool writer = nok && (c & Dm1) == Dm1;                 // this lane holds an example's last column
+    // addresses as a wave-uniform base + ONE 32-bit lane offset that serves every row (16 x MT 64-bit lane addresses do not
+    // fit beside the accumulators: hipcc then spills accumulator tiles to scratch)
+    const unsigned out_off = (unsigned)(hh ? 4 * N : 0) + (unsigned)nc;                       // element offset from row frag_row(r, 0)
+    const unsigned res_lane = (unsigned)((nc >> E.logD) * E.ldres) + (unsigned)(4 * hh);     // example's row of res + the half's 4 rows
+    const bool res_vec = E.res && ((E.ldres | (long)E.res_off | (long)E.dir0) & 3) == 0 && (((size_t)E.res) & 15) == 0;
+    const int keep_rows = E.keep_rows < H ? E.keep_rows : H;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         __builtin_amdgcn_sched_barrier(0);          // one row tile at a time: 16 store addresses live, not 16 * MT
+        const int base = (mb * MT + mt) * 32;       // wave-uniform, like every condition on rows below
+        float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = (mb * MT + mt) * 32 + frag_row(r, hh);
-            float v = acc[mt][r] * sc + bias_s[mt * 32 + frag_row(r, hh)];
-            if (act == XDFM_ACT_RELU) v = fmaxf(v, 0.f);
-            if (row < H && nok && (!(dbg & 1) || acc[mt][r] == 12345.f)) out[(long)row * N + n] = v;
+            v[r] = acc[mt][r] * sc + bias_s[mt * 32 + frag_row(r, hh)];
+            if (act == XDFM_ACT_RELU) v[r] = fmaxf(v[r], 0.f);
+        }
+        // ---- the rows that are kept (all of them, or the hidden half): one lane mask for the whole tile when it is inside
+        if (base + 32 <= keep_rows) {
+            if (nok && !(dbg & 1)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) (out + (long)(base + frag_row(r, 0)) * N)[out_off] = v[r];
+            }
+        } else if (base < keep_rows) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (base + frag_row(r, hh) < keep_rows && nok && !(dbg & 1)) (out + (long)(base + frag_row(r, 0)) * N)[out_off] = v[r];
+        }
+        // ---- ReLU sign bits: a ballot per register = the 32-column words of rows frag_row(r, 0) and + 4; they are dealt
+        // to the lanes (lane = row of the tile) and leave with one store
+        if (E.mask && !(dbg & 64)) {
+            unsigned mw = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned long long bits = __ballot(nok && v[r] > 0.f);
+                mw = lane == frag_row(r, 0) ? (unsigned)bits : mw;
+                mw = lane == frag_row(r, 0) + 4 ? (unsigned)(bits >> 32) : mw;
+            }
+            if (lane < 32 && base + lane < H && wcol < N) E.mask[(long)(base + lane) * E.mask_ld + (wcol >> 5)] = mw;
+        }
+        // ---- direct-connect sums: over the D lanes of an example, log2(D) DPP steps (row_shr 1, 2, 4, 8 inside a row of 16
+        // lanes; fixed order); the lane with an example's last column holds its sum.  Registers 4g .. 4g+3 are four
+        // consecutive rows: one 16-byte store per example and group.
+        if (E.res && base + 32 > E.dir0 && !(dbg & 128)) {
+            const bool inside = base >= E.dir0 && base + 32 <= H && res_vec;
+            float* __restrict__ res_t = E.res + (E.res_off + base - E.dir0);       // wave-uniform
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float s4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = v[4 * g4 + q];
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x111, 0xf, 0xf, true));
+                    t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x112, 0xf, 0xf, true));
+                    if (E.logD > 2) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x114, 0xf, 0xf, true));
+                    if (E.logD > 3) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x118, 0xf, 0xf, true));
+                    s4[q] = t;
+                }
+                float* dst = res_t + 8 * g4 + res_lane;                           // rows base + 8 g4 + 4 hh .. + 3
+                if (inside) {
+                    if (writer) *reinterpret_cast<float4*>(dst) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+                } else if (writer) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = base + 8 * g4 + 4 * hh + q;
+                        if (row >= E.dir0 && row < H) dst[q] = s4[q];
+                    }
+                }
+            }
         }
     }
     if ((dbg & 4) && threadIdx.x == 0 && blockIdx.y == 0) {
@@ -401,7 +465,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
 // workgroup streams the whole packed matrix: 512 x 1.7 MB per launch at config 2 with 4 waves)
 template <int MT, int M, int NT, bool SYM = false>
 static int launch_x3(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, long N,
-                     const X3Geom& g, int act, float* out, hipStream_t st) {
+                     const X3Geom& g, int act, float* out, const X3FwdEpi& epi, hipStream_t st) {
     constexpr int FR = (NT == 3 ? 2 : 1) * MT;
     constexpr int NWMAX = FR % 8 == 0 ? 8 : 4;
     static_assert(FR % 4 == 0, "a ring stage is dealt to 4 or 8 waves");
@@ -413,33 +477,33 @@ static int launch_x3(const float* xp, const float* x0, const float* pack, const 
             const size_t ldsx = RING + 32 * MT * sizeof(float) + (size_t)2 * 8 * 32 * NWMAX * sizeof(float);
             if constexpr (MT == 4 && M == 26 && NT == 3 && !SYM) {
                 const int e = (act >> 8) >> 3;          // dbg bits 8 / 16 / 32 -> EXP 1 / 2 / 4 (7 = all three)
-#define X3_EXP_CASE(E) if (e == E) { hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT, E>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out); return xdfm_check_launch("cin_level_fwd (experiment)"); }
+#define X3_EXP_CASE(E) if (e == E) { hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT, E>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out, epi); return xdfm_check_launch("cin_level_fwd (experiment)"); }
                 X3_EXP_CASE(1) X3_EXP_CASE(2) X3_EXP_CASE(3) X3_EXP_CASE(4) X3_EXP_CASE(5) X3_EXP_CASE(6) X3_EXP_CASE(7)
 #undef X3_EXP_CASE
             }
-            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT, 0, SYM>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out);
+            hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, NWMAX, X3_RING, NT, 0, SYM>), grid, block, ldsx, st, xp, x0, pack, bias, H, Hp, N, g, act, out, epi);
             return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
         }
     }
     const size_t lds4 = RING + 32 * MT * sizeof(float) + (size_t)2 * 8 * 128 * sizeof(float);
     hipLaunchKernelGGL((cin_fwd_x3_kernel<MT, M, 4, X3_RING, NT, 0, SYM>), dim3(ceil_div(N, 128), g.MB), dim3(256), lds4, st, xp, x0, pack,
-                       bias, H, Hp, N, g, act, out);
+                       bias, H, Hp, N, g, act, out, epi);
     return xdfm_check_launch("cin_level_fwd (f16x3 / bf16)");
 }
 
 
 // the instances of one field count: MT row tiles per wave by the geometry, nt MFMA terms by the arithmetic
 #define X3_FWD_DISPATCH_M(MV)                                                                                          \
-    (nt == 3 ? (g.MT == 2   ? launch_x3<2, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                        \
-                : g.MT == 4 ? launch_x3<4, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                        \
-                            : launch_x3<8, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, st))                       \
-             : (g.MT == 4 ? launch_x3<4, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                          \
-                          : launch_x3<8, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)))
+    (nt == 3 ? (g.MT == 2   ? launch_x3<2, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st)                        \
+                : g.MT == 4 ? launch_x3<4, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st)                        \
+                            : launch_x3<8, MV, 3>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st))                       \
+             : (g.MT == 4 ? launch_x3<4, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st)                          \
+                          : launch_x3<8, MV, 1>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st)))
 
 // level 0 with folded weights (x_prev is x0): same choice of instance, SYM kernels
 #define X3_FWD_DISPATCH_SYM(MV)                                                                                        \
-    (nt == 3 ? (g.MT == 2   ? launch_x3<2, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                  \
-                : g.MT == 4 ? launch_x3<4, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                  \
-                            : launch_x3<8, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st))                 \
-             : (g.MT == 4 ? launch_x3<4, MV, 1, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)                    \
-                          : launch_x3<8, MV, 1, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, st)))
+    (nt == 3 ? (g.MT == 2   ? launch_x3<2, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st)                  \
+                : g.MT == 4 ? launch_x3<4, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st)                  \
+                            : launch_x3<8, MV, 3, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st))                 \
+             : (g.MT == 4 ? launch_x3<4, MV, 1, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st)                    \
+                          : launch_x3<8, MV, 1, true>(xp, x0, pack, bias, H, Hp, N, g, act, out, epi, st)))

@@ -3,7 +3,7 @@
 #include "cin_x3_fwd.h"
 
 int x3_level_fwd_ma(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
-                    const X3Geom& g, int nt, int act, float* out, hipStream_t st) {
+                    const X3Geom& g, int nt, int act, float* out, const X3FwdEpi& epi, hipStream_t st) {
     switch (m) {
         case 8: return X3_FWD_DISPATCH_M(8);
         case 10: return X3_FWD_DISPATCH_M(10);

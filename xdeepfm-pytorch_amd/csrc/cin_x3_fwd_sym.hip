@@ -3,7 +3,7 @@
 #include "cin_x3_fwd.h"
 
 int x3_level_fwd_sym(const float* x0, const float* pack, const float* bias, int H, int m, long N, const X3Geom& g, int nt,
-                     int act, float* out, hipStream_t st) {
+                     int act, float* out, const X3FwdEpi& epi, hipStream_t st) {
     const float* xp = x0;
     const int Hp = m;
     if (m == 26) return X3_FWD_DISPATCH_SYM(26);

@@ -158,21 +158,35 @@ struct X3Geom {
     int FB, RH, TS, NS;   // full blocks, rows per lane half / steps of the ragged last block, total steps
     int SPS, NSA;         // steps per ring stage; steps stored per row group (whole stages + one spare, zero past NS)
 };
+// What the f16x3 / bf16 forward kernel does with a level's output besides (or instead of) storing it (xdfm_cin_level_fwd_ex):
+//   keep_rows  rows [0, keep_rows) are stored to `out` (pitch N); rows beyond exist only in the accumulators.  The CIN
+//              stores its hidden half (the next level's x_prev) and, in sum pooling, nothing of its direct-connect half:
+//              those rows are consumed right here by
+//   res        res[b * ldres + res_off + row - dir0] = sum_d out[row][b * D + d] for rows >= dir0 (interaction.py:245-246),
+//              D = 1 << logD in {4, 8, 16}: a D-lane segment sum in the accumulator layout (lane = column), and
+//   mask       bit (n & 31) of mask[row * mask_ld + (n >> 5)] = out[row][n] > 0: all the backward needs of a ReLU level's
+//              saved output once x_prev is saved apart (1 bit instead of 4 bytes per element, written and read).
+struct X3FwdEpi {
+    int keep_rows;
+    float* res; long ldres; int res_off, dir0, logD;
+    unsigned* mask; long mask_ld;
+};
+static inline X3FwdEpi x3_fwd_epi_plain(int H) { return X3FwdEpi{H, nullptr, 0, 0, 0, 0, nullptr, 0}; }
 X3Geom x3_fwd_geom(int H, int Hp, int m);
 X3Geom x3_fwd_geom_sym(int H, int m);          // level 0 with folded weights (x3_sym_*): one block of x3_sym_steps(m) steps
 bool x3_fwd_usable(int H, int Hp, int m);
 size_t x3_fwd_pack_elems(int H, int Hp, int m);
 int x3_fwd_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
 int x3_level_fwd(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
-                 int act, float* out, hipStream_t st);
+                 int act, float* out, const X3FwdEpi& epi, hipStream_t st);
 // level 0 with folded weights (cin_x3_fwd_sym.hip; m with x3_sym_m): `pack` = the folded pack, g = x3_fwd_geom_sym
 int x3_level_fwd_sym(const float* x0, const float* pack, const float* bias, int H, int m, long N, const X3Geom& g, int nt,
-                     int act, float* out, hipStream_t st);
+                     int act, float* out, const X3FwdEpi& epi, hipStream_t st);
 // instances for the other even field counts (cin_x3_fwd_ma.hip: m < 22, cin_x3_fwd_mb.hip: 22 < m <= 40)
 int x3_level_fwd_ma(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
-                    const X3Geom& g, int nt, int act, float* out, hipStream_t st);
+                    const X3Geom& g, int nt, int act, float* out, const X3FwdEpi& epi, hipStream_t st);
 int x3_level_fwd_mb(const float* xp, const float* x0, const float* pack, const float* bias, int H, int Hp, int m, long N,
-                    const X3Geom& g, int nt, int act, float* out, hipStream_t st);
+                    const X3Geom& g, int nt, int act, float* out, const X3FwdEpi& epi, hipStream_t st);
 struct X3BwxGeom {
     int HBT, HBS, IB;     // h-blocks (of 16) in total / per ring stage, i-blocks (of 32)
     long NT;              // tiles = IB * m
@@ -231,7 +245,7 @@ int x3_level_bwd_w(const float* dOut, const float* xp, const float* x0, int H, i
                    float* dW, bool prepared, hipStream_t st);
 // cin_dout that also leaves the dW kernel's operands (planes, per-split scales) in the dW workspace (cin_x3_bww.hip)
 int x3_bwd_prep_blocks(bool xp_is_x0, int H, int Hp, int m, long N);      // dbias partials per row
-int x3_bwd_prep(const float* A, int H, long N, int D, int act, const float* dHid, int hid0, int hid_rows, const float* dDir,
+int x3_bwd_prep(const float* A, const unsigned* mask, long mask_ld, int H, long N, int D, int act, const float* dHid, int hid0, int hid_rows, const float* dDir,
                 int dir_mode, long lddir, int dir_off, int dir0, int dir_rows, float* dOut, float* slots, float* dbias,
                 unsigned* ticket, const float* xp, const float* x0, int Hp, int m, float* ws, hipStream_t st);
 

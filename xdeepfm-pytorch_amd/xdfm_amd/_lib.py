@@ -41,8 +41,11 @@ SIGNATURES = {
     "xdfm_cin_dout_det": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int,
                                   c_int, P, P, P, P]),
     "xdfm_cin_bwd_prep_ws_elems": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "xdfm_cin_bwd_prep": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int, c_int, P, P, P,
+    "xdfm_cin_bwd_prep": (c_int, [P, P, c_long, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_long, c_int, c_int, c_int, P, P, P,
                                   P, P, c_int, c_int, P, P, P]),
+    "xdfm_cin_level_fwd_ex_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "xdfm_cin_level_fwd_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_int, P, c_int, P, c_long, c_int, c_int, c_int,
+                                      P, c_long, P]),
     "xdfm_cin_level_bwd_w_prepared": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_bwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),
@@ -55,6 +58,9 @@ SIGNATURES = {
     "xdfm_cin_attn_pool_fwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, c_float, P, P]),
     "xdfm_cin_attn_pool_bwd": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, c_float,
                                        P, P]),
+    "xdfm_cin_attn_pool_bwd_ws_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "xdfm_cin_attn_pool_bwd_det": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_float,
+                                           P, P]),
     "xdfm_cin_attn_dropout_mask": (c_int, [c_int, c_int, c_int, c_int, c_float, P, P, P]),
     "xdfm_head_ws_elems": (c_size_t, [c_int, c_int]),
     "xdfm_head_fwd": (c_int, [P, P, P, c_int, P, P, c_int, P, P, c_int, P, P, P, P]),

@@ -381,6 +381,15 @@ class CINStack(torch.autograd.Function):
             _lib.check(lib.xdfm_cin_pack_all(ctypes.cast(jobs, ctypes.c_void_p), len(levels), _stream()), "cin_pack_all")
             if not need_bwd:
                 wzs = None
+        # "lean" levels (sum pooling, f16x3 / bf16 forward, D in {4, 8, 16}): the forward's epilogue sums the direct-connect
+        # rows into `result` and leaves the ReLU sign bits, so only the hidden rows (the next level's x_prev) are ever
+        # written -- no direct_sum launches, no direct-connect half in memory, and the backward reads 1 bit per element
+        # instead of the saved output (xdfm_cin_level_fwd_ex / xdfm_cin_bwd_prep)
+        lean = pool == "sum" and os.environ.get("XDFM_CIN_LEAN", "1") != "0" and \
+            all(lib.xdfm_cin_level_fwd_ex_supported(H, Hp, m, D) for (H, Hp, *_r) in levels)
+        need_bwd = any(ctx.needs_input_grad)
+        masks = []
+        mask_ld = (N + 31) // 32
         for l, (H, Hp, hid, dir0, drows, off) in enumerate(levels):
             W, bias = params[2 * l], params[2 * l + 1]
             W2 = W2s[l]
@@ -388,8 +397,18 @@ class CINStack(torch.autograd.Function):
             if wf is None:
                 wf = torch.empty(lib.xdfm_cin_fwd_pack_elems(H, Hp, m), dtype=torch.float32, device=dev)
                 _lib.check(lib.xdfm_cin_fwd_pack(_ptr(W2), H, Hp, m, _ptr(wf), _stream()), "cin_fwd_pack")
-            A = torch.empty((H, N), dtype=torch.float32, device=dev)
             bias_c = bias.contiguous()
+            if lean:
+                A = torch.empty((hid, N), dtype=torch.float32, device=dev) if hid > 0 else None
+                mk = torch.empty((H, mask_ld), dtype=torch.int32, device=dev) if need_bwd else None
+                _lib.check(_run("cin_level_fwd", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_fwd_ex(
+                    _ptr(xp), _ptr(x0), _ptr(wf), _ptr(bias_c), H, Hp, m, N, act, _ptr(A), hid, _ptr(result), fm, off, dir0, D,
+                    _ptr(mk), mask_ld, _stream())), "cin_level_fwd")
+                masks.append(mk)
+                outs.append(A if A is not None else x0[:0])      # a placeholder keeps the saved-tensor list regular
+                xp = A
+                continue
+            A = torch.empty((H, N), dtype=torch.float32, device=dev)
             _lib.check(_run("cin_level_fwd", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_fwd(
                 _ptr(xp), _ptr(x0), _ptr(wf), _ptr(bias_c), H, Hp, m, N, act, _ptr(A), _stream())), "cin_level_fwd")
             _warn_if_fp32_fallback("forward", "last_fwd_kernel", H, Hp, m)
@@ -401,7 +420,11 @@ class CINStack(torch.autograd.Function):
         ctx.cfg = (B, D, tuple(layer_size), split_half, act, pool, m)
         ctx.wzs = wzs                                # dX packs made up front (or None), arithmetic mode they belong to
         ctx.cin_math = _lib.get_option("cin_math")
-        ctx.save_for_backward(x0, *outs, *params)
+        ctx.lean = lean and need_bwd
+        if ctx.lean:
+            ctx.save_for_backward(x0, *outs, *params, *masks)
+        else:
+            ctx.save_for_backward(x0, *outs, *params)
         if pool == "sum":
             return result
         return torch.cat([A[dir0:dir0 + drows] for A, (H, Hp, hid, dir0, drows, off) in zip(outs, levels)], dim=0)
@@ -412,7 +435,8 @@ class CINStack(torch.autograd.Function):
         B, D, layer_size, split_half, act, pool, m = ctx.cfg
         L = len(layer_size)
         saved = ctx.saved_tensors
-        x0, outs, params = saved[0], saved[1:1 + L], saved[1 + L:]
+        x0, outs, params = saved[0], saved[1:1 + L], saved[1 + L:1 + 3 * L]
+        masks = saved[1 + 3 * L:] if ctx.lean else None        # lean levels: outs[l] holds the hidden rows only, the ReLU mask is bits
         N = B * D
         dev = x0.device
         levels, fm = cin_geometry(m, layer_size, split_half)
@@ -425,7 +449,8 @@ class CINStack(torch.autograd.Function):
         dbias_off = [sum(lv[0] for lv in levels[:k]) for k in range(L)]
         for l in range(L - 1, -1, -1):
             H, Hp, hid, dir0, drows, off = levels[l]
-            A = outs[l]
+            A = None if ctx.lean else outs[l]
+            mk = masks[l] if ctx.lean else None
             xp = x0 if l == 0 else outs[l - 1][:levels[l - 1][2]]
             W, bias = params[2 * l], params[2 * l + 1]
             dOut = torch.empty((H, N), dtype=torch.float32, device=dev)
@@ -438,7 +463,7 @@ class CINStack(torch.autograd.Function):
             ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m, N), dtype=torch.float32, device=dev) if need_dw else None
             prepared = ctypes.c_int(0)
             _lib.check(_run("cin_dout", 0.0, lambda: lib.xdfm_cin_bwd_prep(
-                _ptr(A), H, B, D, act, _ptr(dhid) if has_hid else None, 0, hid if has_hid else 0, _ptr(g),
+                _ptr(A), _ptr(mk), (N + 31) // 32, H, B, D, act, _ptr(dhid) if has_hid else None, 0, hid if has_hid else 0, _ptr(g),
                 0 if pool == "sum" else 1, fm if pool == "sum" else N, off, dir0, drows, _ptr(dOut), _ptr(dbias), _ptr(dws),
                 _ptr(xp), _ptr(x0), Hp, m, _ptr(ws), ctypes.byref(prepared), _stream())), "cin_dout")
             if need_dw:
@@ -558,12 +583,13 @@ class AttnPool(torch.autograd.Function):
         seed = ctx.drop_seed
         S = fm.shape[0]
         dfm = torch.empty_like(fm)
-        dtheta = torch.zeros_like(theta)
+        dtheta = torch.empty_like(theta)         # overwritten: per-workgroup shares + a fixed-order sum, no float atomics
+        ws = torch.empty(lib.xdfm_cin_attn_pool_bwd_ws_elems(B, D, n_layers, int(use_ln)), dtype=torch.float32, device=fm.device)
         dout = dout.contiguous()
         flops = 2.0 * 7 * D * S * S * B * n_layers
-        _lib.check(_run("cin_attn_pool_bwd", flops, lambda: lib.xdfm_cin_attn_pool_bwd(
+        _lib.check(_run("cin_attn_pool_bwd", flops, lambda: lib.xdfm_cin_attn_pool_bwd_det(
             _ptr(fm), B, S, D, nh, n_layers, int(use_ln), int(use_res), _ptr(theta), _ptr(tok), _ptr(osv), _ptr(ml),
-            _ptr(dout), _ptr(dfm), _ptr(dtheta), p_drop, _ptr(seed) if seed is not None else None, _stream())),
+            _ptr(dout), _ptr(dfm), _ptr(dtheta), _ptr(ws), p_drop, _ptr(seed) if seed is not None else None, _stream())),
             "cin_attn_pool_bwd")
         grads, off = [], 0
         for sh in shapes:
