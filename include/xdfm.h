@@ -179,7 +179,8 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
  * D in {4, 8, 16}: xdfm_cin_level_fwd_ex_supported): rows [0, keep_rows) are stored to out [keep_rows][N]; rows >= dir0 are
  * summed over the embedding axis into res (res[b * ldres + res_off + row - dir0], interaction.py:245-246: the
  * direct-connect half of a level in sum pooling is never written out), res == NULL: no sums; mask != NULL: bit n & 31 of
- * mask[row * mask_ld + (n >> 5)] = out[row][n] > 0 for every row (all the backward needs of a ReLU level's output).
+ * mask[(n >> 5) * mask_ld + row] = out[row][n] > 0 for every row (mask_ld >= H, a multiple of 4; mask 16-byte aligned: all
+ * the backward needs of a ReLU level's output).
  * At BASELINE config 2 this removes 84 MB of stores, the three xdfm_cin_direct_sum launches and their 84 MB of reads, and
  * (with the mask given to xdfm_cin_bwd_prep) 134 MB of reads in the backward, per step. */
 int xdfm_cin_level_fwd_ex_supported(int H, int Hp, int m, int D);
@@ -248,10 +249,18 @@ int xdfm_cin_level_bwd_w(const float* dOut, const float* xp, const float* x0,
  * x0, shapes, workspace and options; 0 when the shape has no f16x3 / bf16 dW kernel (H <= 64, D % 4 != 0, unaligned
  * rows, cin_math 0): the call then was xdfm_cin_dout_det and xdfm_cin_level_bwd_w does its own passes.
  * dout_ws: xdfm_cin_bwd_prep_ws_elems floats (dbias partials, added up in a fixed order).  dbias is added to.
- * mask != NULL: the ReLU mask comes from the sign bits xdfm_cin_level_fwd_ex left (bit n & 31 of mask[h * mask_ld + (n >> 5)]
+ * mask != NULL: the ReLU mask comes from the sign bits xdfm_cin_level_fwd_ex left (bit n & 31 of mask[(n >> 5) * mask_ld + h]
  * = out[h][n] > 0) and A is not read (may be NULL): the level's output then need not be kept at all beyond its hidden
  * rows, which travel as xp. */
 size_t xdfm_cin_bwd_prep_ws_elems(int H, int Hp, int m, int B, int D);
+/* dOut == NULL in xdfm_cin_bwd_prep (allowed when xdfm_cin_bwd_nodout_supported and a mask is given): the fp32 dOut is not
+ * written at all -- the dW kernel takes the planes, and the dX kernel forms its dOut operand itself, from the very
+ * sources of this pass (xdfm_cin_level_bwd_x_src: sign bits, dHid, pooled gradient).  67 MB less written and 67 MB less
+ * read at level 0 of config 2.  xdfm_cin_level_bwd_x_src: one call covers rows [h0, h0 + H) of the level, H <= 256. */
+int xdfm_cin_bwd_nodout_supported(int H, int Hp, int m, int B, int D);
+int xdfm_cin_level_bwd_x_src(const unsigned* mask, long mask_ld, const float* dHid, int hid_rows, const float* dDir, int dir_mode,
+                             long lddir, int dir_off, int dir0, int dir_rows, int D, int h0, const float* xp, const float* x0,
+                             const float* Wz, int H, int Hp, int m, long N, float* dxp, float* dx0, int flags, void* stream);
 int xdfm_cin_bwd_prep(const float* A, const unsigned* mask, long mask_ld, int H, int B, int D, int act, const float* dHid,
                       int hid0, int hid_rows, const float* dDir, int dir_mode, long lddir, int dir_off, int dir0, int dir_rows,
                       float* dOut, float* dbias, float* dout_ws, const float* xp, const float* x0, int Hp, int m, float* bww_ws,

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
     const bool has_hid = dHid && h >= hid0 && h < hid0 + hid_rows;
     const bool has_dir = dDir && h >= dir0 && h < dir0 + dir_rows;
     const float* __restrict__ arow = mask ? dOut : A + (long)h * N;        // with sign bits (X3FwdEpi.mask) the saved output is not read
-    const unsigned* __restrict__ mrow = mask ? mask + (long)h * mask_ld : nullptr;
+    const unsigned* __restrict__ mrow = mask ? mask + h : nullptr;         // word of chunk q: mrow[q * mask_ld]
     const float* __restrict__ hrow = has_hid ? dHid + (long)(h - hid0) * N : nullptr;
     const float* __restrict__ drow = (has_dir && dir_mode == 1) ? dDir + (long)(dir_off + h - dir0) * N : nullptr;
     const float* __restrict__ dres = (has_dir && dir_mode == 0) ? dDir + dir_off + (h - dir0) : nullptr;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
             float g[VEC], a[VEC];
             if constexpr (VEC == 4) {
                 if (mrow) {
-                    const unsigned w = mrow[n >> 5] >> (n & 31);
+                    const unsigned w = mrow[(n >> 5) * mask_ld] >> (n & 31);
                     a[0] = (w & 1u) ? 1.f : 0.f; a[1] = (w & 2u) ? 1.f : 0.f; a[2] = (w & 4u) ? 1.f : 0.f; a[3] = (w & 8u) ? 1.f : 0.f;
                 } else {
                     const float4 av = *reinterpret_cast<const float4*>(arow + n);
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void cin_dout_kernel(
                     g[0] += r; g[1] += r; g[2] += r; g[3] += r;
                 }
             } else {
-                a[0] = mrow ? (((mrow[n >> 5] >> (n & 31)) & 1u) ? 1.f : 0.f) : arow[n];
+                a[0] = mrow ? (((mrow[(n >> 5) * mask_ld] >> (n & 31)) & 1u) ? 1.f : 0.f) : arow[n];
                 g[0] = hrow ? hrow[n] : 0.f;
                 if (drow) g[0] += drow[n];
                 if (dres) g[0] += dres[(n / D) * lddir];
@@ -835,7 +835,7 @@ int xdfm_cin_level_bwd_x_ex(const float* dOut, const float* xp, const float* x0,
     XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_x: bad shape H=%d (<=256) Hp=%d m=%d",
                  H, Hp, m);
     hipStream_t st = (hipStream_t)stream;
-    if (x3_bwx_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_BWX, xdfm_opt(OPT_CIN_MATH)); return x3_level_bwd_x(dOut, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st); }
+    if (x3_bwx_usable(H, Hp, m)) { xdfm_opt_note(OPT_LAST_BWX, xdfm_opt(OPT_CIN_MATH)); return x3_level_bwd_x(x3_dout_plain(dOut), xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, st); }
     xdfm_opt_note(OPT_LAST_BWX, 0);
     xdfm_opt_note(OPT_LAST_SYM, xdfm_opt(OPT_LAST_SYM) & ~2);
     switch (bwx_hs4(H)) {
@@ -901,13 +901,14 @@ int xdfm_cin_bwd_prep(const float* A, const unsigned* mask, long mask_ld, int H,
                       float* dOut, float* dbias, float* dout_ws, const float* xp, const float* x0, int Hp, int m, float* bww_ws,
                       int* prepared, void* stream) {
     XDFM_REQUIRE(prepared, "cin_bwd_prep: null pointer");
-    XDFM_REQUIRE(!mask || mask_ld >= ((long)B * D + 31) / 32, "cin_bwd_prep: mask pitch %ld", mask_ld);
+    XDFM_REQUIRE(!mask || (mask_ld >= H && mask_ld % 4 == 0), "cin_bwd_prep: mask pitch %ld", mask_ld);
     *prepared = 0;
     const long N = (long)B * D;
     const float* dh = hid_rows > 0 ? dHid : nullptr;
     const float* dd = dir_rows > 0 ? dDir : nullptr;
-    const bool fused = dout_ws && bww_ws && xp && x0 && Hp > 0 && m > 0 && H > 0 && B > 0 && D > 0 && (A || mask) && dOut &&
+    const bool fused = dout_ws && bww_ws && xp && x0 && Hp > 0 && m > 0 && H > 0 && B > 0 && D > 0 && (A || mask) && (dOut || mask) &&
                        x3_bww_usable(dOut, xp, x0, H, N) && cin_dout_vec(mask ? dOut : A, N, D, dOut, dh, dir_mode == 1 ? dd : nullptr);
+    XDFM_REQUIRE(fused || dOut, "cin_bwd_prep: dOut may only be omitted when the pass is fused (xdfm_cin_bwd_nodout_supported)");
     if (!fused)
         return cin_dout_impl(A, mask, mask_ld, H, B, D, act, dHid, hid0, hid_rows, dDir, dir_mode, lddir, dir_off, dir0, dir_rows, dOut,
                              dbias, dout_ws, stream);
@@ -928,9 +929,35 @@ int xdfm_cin_bwd_prep(const float* A, const unsigned* mask, long mask_ld, int H,
     return xdfm_check_launch("cin_bwd_prep");
 }
 
+int xdfm_cin_bwd_nodout_supported(int H, int Hp, int m, int B, int D) {
+    const long N = (long)B * D;
+    return (H > 0 && Hp > 0 && m > 0 && B > 0 && (D == 4 || D == 8 || D == 16) && x3_terms() != 0 && bww_mt(H) == 4 && N % 4 == 0 &&
+            N >= 32 && x3_bwx_usable(H < 256 ? H : 256, Hp, m) && (H <= 256 || H % 256 == 0 || x3_bwx_usable(H % 256, Hp, m)) &&
+            H <= (1 << 16)) ? 1 : 0;
+}
+
+int xdfm_cin_level_bwd_x_src(const unsigned* mask, long mask_ld, const float* dHid, int hid_rows, const float* dDir, int dir_mode,
+                             long lddir, int dir_off, int dir0, int dir_rows, int D, int h0, const float* xp, const float* x0,
+                             const float* Wz, int H, int Hp, int m, long N, float* dxp, float* dx0, int flags, void* stream) {
+    XDFM_REQUIRE(xp && x0 && Wz && dxp && dx0 && (dHid || dDir), "cin_level_bwd_x_src: null pointer");
+    XDFM_REQUIRE((flags & ~(XDFM_BWX_SET_DXP | XDFM_BWX_SET_DX0)) == 0, "cin_level_bwd_x_src: unknown flags 0x%x", flags);
+    XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0 && N > 0 && h0 >= 0 && h0 % 4 == 0, "cin_level_bwd_x_src: bad shape H=%d (<=256) Hp=%d m=%d h0=%d",
+                 H, Hp, m, h0);
+    XDFM_REQUIRE(x3_bwx_usable(H, Hp, m), "cin_level_bwd_x_src: no f16x3 / bf16 dX kernel for H=%d", H);
+    XDFM_REQUIRE(D == 4 || D == 8 || D == 16, "cin_level_bwd_x_src: D=%d", D);
+    XDFM_REQUIRE(!mask || (mask_ld >= h0 + H && mask_ld % 4 == 0 && (((size_t)mask) & 15) == 0), "cin_level_bwd_x_src: mask pitch %ld", mask_ld);
+    XDFM_REQUIRE(dir_mode == 0 || dir_mode == 1, "cin_level_bwd_x_src: dir_mode %d", dir_mode);
+    int logD = 0;
+    while ((1 << logD) < D) ++logD;
+    const X3DoutSrc S = {nullptr, mask, mask_ld, hid_rows > 0 ? dHid : nullptr, hid_rows, dir_rows > 0 ? dDir : nullptr, dir_mode, lddir,
+                         dir_off, dir0, dir_rows, logD, h0};
+    xdfm_opt_note(OPT_LAST_BWX, xdfm_opt(OPT_CIN_MATH));
+    return x3_level_bwd_x(S, xp, x0, Wz, H, Hp, m, N, dxp, dx0, flags, (hipStream_t)stream);
+}
+
 int xdfm_cin_level_bwd_w_prepared(const float* dOut, const float* xp, const float* x0, int H, int Hp, int m, long N,
                                   float* ws, float* dW, void* stream) {
-    XDFM_REQUIRE(dOut && xp && x0 && ws && dW, "cin_level_bwd_w: null pointer");
+    XDFM_REQUIRE(xp && x0 && ws && dW, "cin_level_bwd_w: null pointer");       // dOut itself is not read (may be NULL): the planes are
     XDFM_REQUIRE(H > 0 && Hp > 0 && m > 0 && N > 0, "cin_level_bwd_w: bad shape H=%d Hp=%d m=%d", H, Hp, m);
     XDFM_REQUIRE(x3_bww_usable(dOut, xp, x0, H, N), "cin_level_bwd_w_prepared: no f16x3 / bf16 dW kernel for this call (H=%d)", H);
     xdfm_opt_note(OPT_LAST_BWW, xdfm_opt(OPT_CIN_MATH));

@@ -484,7 +484,7 @@ int xdfm_cin_level_fwd_ex(const float* xp, const float* x0, const float* Wf, con
     XDFM_REQUIRE(keep_rows >= 0 && keep_rows <= H && (keep_rows == 0 || out), "cin_level_fwd_ex: keep_rows %d of %d", keep_rows, H);
     XDFM_REQUIRE(!res || (dir0 >= 0 && dir0 <= H && ldres >= res_off + (H - dir0) && res_off >= 0 && N % D == 0),
                  "cin_level_fwd_ex: bad direct-sum arguments");
-    XDFM_REQUIRE(!mask || mask_ld >= (N + 31) / 32, "cin_level_fwd_ex: mask pitch %ld", mask_ld);
+    XDFM_REQUIRE(!mask || (mask_ld >= H && mask_ld % 4 == 0), "cin_level_fwd_ex: mask pitch %ld", mask_ld);
     int logD = 0;
     while ((1 << logD) < D) ++logD;
     const X3FwdEpi epi = {keep_rows, res, ldres, res_off, res ? dir0 : H, logD, mask, mask_ld};

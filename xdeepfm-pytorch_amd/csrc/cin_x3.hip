@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void x3_pack_multi_kernel(const X3PackJobs J) 
 
 template <int HBT, int NW, int NT = 3>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
-    const float* __restrict__ dOut, const float* xp, const float* x0, const float* __restrict__ pack,
+    const X3DoutSrc S, const float* xp, const float* x0, const float* __restrict__ pack,
     int H, int Hp, int m, long N, int IB, float* dxp, float* dx0, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int HBS = HBT > 8 ? 8 : HBT;      // h-blocks per stage
@@ -502,13 +502,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_kernel(
     float sD = 1.f;
     {
         float raw[8 * HBT];
-#pragma unroll
-        for (int hb = 0; hb < HBT; ++hb)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int h = 16 * hb + 8 * hh + t;
-                raw[8 * hb + t] = dOut[(long)(h < H ? h : H - 1) * N + nc];
-            }
+        x3_load_dout<HBT>(raw, S, H, N, nc, n0, lane, c, hh);
         float dmax = 0.f;
 #pragma unroll
         for (int hb = 0; hb < HBT; ++hb)
@@ -724,7 +718,7 @@ int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t s
 }
 
 template <int HBT, int NT>
-static int launch_bwx3(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m,
+static int launch_bwx3(const X3DoutSrc& dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m,
                        long N, const X3BwxGeom& g, float* dxp, float* dx0, int flags, hipStream_t st) {
     constexpr int HBS = HBT > 8 ? 8 : HBT;
     constexpr int FR = HBS * (NT == 3 ? 2 : 1);
@@ -742,7 +736,7 @@ static int launch_bwx3(const float* dOut, const float* xp, const float* x0, cons
     return xdfm_check_launch("cin_level_bwd_x (f16x3 / bf16)");
 }
 
-int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
+int x3_level_bwd_x(const X3DoutSrc& dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
                    float* dxp, float* dx0, int flags, hipStream_t st) {
     const X3BwxGeom g = x3_bwx_geom(H, Hp, m);
     if ((((size_t)pack) & 15) != 0) return xdfm_fail(XDFM_ERR_INVALID, "cin_level_bwd_x: packed weights must be 16-byte aligned");

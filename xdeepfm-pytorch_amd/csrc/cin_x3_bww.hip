@@ -605,18 +605,18 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
     const bool real = is_d ? row < H : (is_xp ? row < Hp : true);
     // the ReLU mask of a dOut row: the sign bits the forward left (X3FwdEpi.mask), or the saved output itself
     const bool use_mask = is_d && mask != nullptr;
-    const unsigned* __restrict__ mrow = use_mask ? mask + (long)(real ? row : 0) * mask_ld : nullptr;
-    const float* __restrict__ src = (is_d ? (use_mask ? dOut : A + (long)(real ? row : 0) * N)
+    const unsigned* __restrict__ mrow = use_mask ? mask + (real ? row : 0) : nullptr;        // word of chunk q: mrow[q * mask_ld]
+    const float* __restrict__ src = (is_d ? (use_mask ? x0 : A + (long)(real ? row : 0) * N)
                                           : (is_xp ? xp + (long)(real ? row : 0) * N : x0 + (long)row * N)) + c0;
     const bool has_hid = is_d && real && dHid && row >= hid0 && row < hid0 + hid_rows;
     const bool has_dir = is_d && real && dDir && row >= dir0 && row < dir0 + dir_rows;
     const float* __restrict__ hrow = has_hid ? dHid + (long)(row - hid0) * N + c0 : nullptr;
     const float* __restrict__ drow = (has_dir && dir_mode == 1) ? dDir + (long)(dir_off + row - dir0) * N + c0 : nullptr;
     const float* __restrict__ dres = (has_dir && dir_mode == 0) ? dDir + dir_off + (row - dir0) : nullptr;
-    float* __restrict__ orow = dOut + (long)(is_d && real ? row : 0) * N + c0;
+    float* __restrict__ orow = dOut ? dOut + (long)(is_d && real ? row : 0) * N + c0 : nullptr;     // null: dOut is not materialised
     // the values of 4 columns at offset o (o % 4 == 0, o < nreal): dOut for a dOut row, the operand itself for x_prev / x0
     auto keep4 = [&](int o) -> float4 {                  // 1.0 where the level's output was > 0 (4 columns at offset o)
-        const unsigned w = mrow[(c0 + o) >> 5] >> ((c0 + o) & 31);
+        const unsigned w = mrow[((c0 + o) >> 5) * mask_ld] >> ((c0 + o) & 31);
         return make_float4((w & 1u) ? 1.f : 0.f, (w & 2u) ? 1.f : 0.f, (w & 4u) ? 1.f : 0.f, (w & 8u) ? 1.f : 0.f);
     };
     auto value = [&](int o) -> float4 {
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
     // waits until the block has drawn its ticket: a block's ticket waits for its outstanding stores, see `finish`)
     auto account = [&](int o, const float4& g0, const float4& g1) {
         if (is_d) {
-            if (!reg) {
+            if (!reg && orow) {
                 *reinterpret_cast<float4*>(orow + o) = g0;
                 if (o + 4 < nreal) *reinterpret_cast<float4*>(orow + o + 4) = g1;
             }
@@ -777,12 +777,15 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
     if (!is_d) return;
     // planes of this row and these columns: [hi 32 halves | lo 32 halves] per 32 columns, zero beyond N and for rows >= H
     char* __restrict__ prow = planes + ((long)y * NP + c0) * 4;
-    for (int it = 0; it < iters; ++it) {
+    const int iters2 = reg ? 2 : iters;              // register path: a fixed, unrolled pair of iterations (static register indices:
+    //                                                  a run-time index into gv turns the array into 16 KB of LDS)
+#pragma unroll 2
+    for (int it = 0; it < iters2; ++it) {
         const int o = (it * 256 + (int)threadIdx.x) * 8;
-        if (o >= span) break;
+        if (o >= span) continue;
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
         if (real) {
-            if (reg) { g0 = gv[it & 1][0]; g1 = gv[it & 1][1]; }
+            if (reg) { g0 = it == 0 ? gv[0][0] : gv[1][0]; g1 = it == 0 ? gv[0][1] : gv[1][1]; }
             else { if (o < nreal) g0 = value(o); if (o + 4 < nreal) g1 = value(o + 4); }
         }
         float sc = 1.f;
@@ -803,7 +806,7 @@ __global__ __launch_bounds__(256) void x3_bwd_prep_kernel(
         char* blk = prow + (long)(o & ~31) * 4 + (o & 31) * 2;
         *reinterpret_cast<h8*>(blk) = hi;
         if (NT == 3) *reinterpret_cast<h8*>(blk + 64) = lo;
-        if (reg && real && o < nreal) {                               // the fp32 dOut the dX kernel reads
+        if (reg && real && o < nreal && orow) {                       // the fp32 dOut the dX kernel reads (unless it forms dOut itself)
             *reinterpret_cast<float4*>(orow + o) = g0;
             if (o + 4 < nreal) *reinterpret_cast<float4*>(orow + o + 4) = g1;
         }

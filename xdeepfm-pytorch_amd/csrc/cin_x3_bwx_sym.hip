@@ -11,7 +11,7 @@
 
 template <int HBT, int NW, int NT, int M>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_sym_kernel(
-    const float* __restrict__ dOut, const float* __restrict__ x0, const float* __restrict__ pack, int H, long N,
+    const X3DoutSrc S, const float* __restrict__ x0, const float* __restrict__ pack, int H, long N,
     float* __restrict__ dxp, float* __restrict__ dx0, int flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     static_assert(M % 2 == 0 && M < 32, "two columns share the 32 rows of a tile");
@@ -79,13 +79,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_sym_kernel(
     float sD = 1.f;
     {
         float raw[8 * HBT];
-#pragma unroll
-        for (int hb = 0; hb < HBT; ++hb)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int h = 16 * hb + 8 * hh + t;
-                raw[8 * hb + t] = dOut[(long)(h < H ? h : H - 1) * N + nc];
-            }
+        x3_load_dout<HBT>(raw, S, H, N, nc, n0, lane, c, hh);
         float dmax = 0.f;
 #pragma unroll
         for (int hb = 0; hb < HBT; ++hb)
@@ -251,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_bwd_x3_sym_kernel(
 }
 
 template <int HBT, int NT, int M>
-static int launch_bwx3_sym(const float* dOut, const float* x0, const float* pack, int H, long N, float* dxp, float* dx0,
+static int launch_bwx3_sym(const X3DoutSrc& dOut, const float* x0, const float* pack, int H, long N, float* dxp, float* dx0,
                            int flags, hipStream_t st) {
     constexpr int HBS = HBT > 8 ? 8 : HBT;
     constexpr int FR = HBS * (NT == 3 ? 2 : 1);
@@ -269,7 +263,7 @@ static int launch_bwx3_sym(const float* dOut, const float* x0, const float* pack
 }
 
 template <int M>
-static int dispatch_bwx3_sym(const float* dOut, const float* x0, const float* pack, int H, long N, int HBT, int nt,
+static int dispatch_bwx3_sym(const X3DoutSrc& dOut, const float* x0, const float* pack, int H, long N, int HBT, int nt,
                              float* dxp, float* dx0, int flags, hipStream_t st) {
     if (nt == 1) {
         switch (HBT) {
@@ -287,7 +281,7 @@ static int dispatch_bwx3_sym(const float* dOut, const float* x0, const float* pa
     }
 }
 
-int x3_level_bwd_x_sym(const float* dOut, const float* x0, const float* pack, int H, int m, long N, int HBT, int nt,
+int x3_level_bwd_x_sym(const X3DoutSrc& dOut, const float* x0, const float* pack, int H, int m, long N, int HBT, int nt,
                        float* dxp, float* dx0, int flags, hipStream_t st) {
     if (m == 26) return dispatch_bwx3_sym<26>(dOut, x0, pack, H, N, HBT, nt, dxp, dx0, flags, st);
     if (m == 22) return dispatch_bwx3_sym<22>(dOut, x0, pack, H, N, HBT, nt, dxp, dx0, flags, st);

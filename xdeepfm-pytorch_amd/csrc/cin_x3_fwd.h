@@ -56,6 +56,83 @@ __device__ __forceinline__ void x3_split_prod2(float a0, float b0, float a1, flo
     lo = __builtin_convertvector(r, h2);
 }
 
+// The lane's 8 * HBT values of dOut (rows h = 16 hb + 8 hh + t of this launch, column nc), zero for rows >= H: read from
+// the materialised tensor, or formed from its sources (X3DoutSrc, xdfm_internal.h).  All loads are unconditional (clamped
+// addresses) and issued before the first use.  lane, c = lane & 31, hh = lane >> 5; n0 = the wave's first column.
+template <int HBT>
+__device__ __forceinline__ void x3_load_dout(float (&raw)[8 * HBT], const X3DoutSrc& S, int H, long N, long nc, long n0, int lane,
+                                             int c, int hh) {
+    if (S.dOut) {
+#pragma unroll
+        for (int hb = 0; hb < HBT; ++hb)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int h = 16 * hb + 8 * hh + t;
+                raw[8 * hb + t] = S.dOut[(long)(h < H ? h : H - 1) * N + nc];
+            }
+        return;
+    }
+    // sign bits of this wave's 32 columns: the chunk's words are contiguous over the rows -- lane L takes rows 4L .. 4L+3
+    uint4 wv = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (S.mask) {
+        const long chunk = n0 >> 5;
+        int r4 = 4 * lane;
+        r4 = r4 + 4 <= (int)S.mask_ld - S.h0 ? r4 : 0;                       // rows past the level: any words (their values are zeroed)
+        wv = *reinterpret_cast<const uint4*>(S.mask + chunk * S.mask_ld + S.h0 + r4);
+    }
+    // Blocks of 16 rows lie -- for every level whose halves are multiples of 16 -- entirely in the hidden part (dHid) or
+    // entirely in the direct-connect part (the pooled gradient): then the 16 loads of a block are a wave-uniform base
+    // plus ONE 32-bit lane offset (128 per-lane 64-bit addresses do not fit beside the 128 values); a block that straddles
+    // a boundary takes the element-wise path.
+    const long bex = nc >> S.logD;
+    const unsigned offh = (unsigned)(hh ? 8 * N : 0) + (unsigned)nc;            // element (row + 8 hh, column nc) from row r0 + t
+    const unsigned offd = (unsigned)(bex * S.lddir) + (unsigned)(8 * hh);       // pooled gradient of this example, rows + 8 hh
+#pragma unroll
+    for (int hb = 0; hb < HBT; ++hb) {
+        const int r0 = S.h0 + 16 * hb;                                           // wave-uniform
+        const bool in_dir = S.dDir && r0 + 16 > S.dir0 && r0 < S.dir0 + S.dir_rows;      // the block touches direct-connect rows
+        const bool in_hid = S.dHid && r0 < S.hid_rows;
+        const bool all_h = in_hid && r0 + 16 <= S.hid_rows && !in_dir;
+        const bool all_d = in_dir && r0 >= S.dir0 && r0 + 16 <= S.dir0 + S.dir_rows && !in_hid;
+        if (all_h) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) raw[8 * hb + t] = (S.dHid + (long)(r0 + t) * N)[offh];
+        } else if (all_d && S.dir_mode == 0) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) raw[8 * hb + t] = (S.dDir + (S.dir_off + r0 + t - S.dir0))[offd];
+        } else if (all_d) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) raw[8 * hb + t] = (S.dDir + (long)(S.dir_off + r0 + t - S.dir0) * N)[offh];
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int hl = r0 + 8 * hh + t;                                  // row of the level
+                float v = 0.f;
+                if (S.dHid && hl < S.hid_rows) v = S.dHid[(long)hl * N + nc];
+                if (S.dDir && hl >= S.dir0 && hl < S.dir0 + S.dir_rows) {
+                    const int r = S.dir_off + hl - S.dir0;
+                    v += S.dir_mode == 0 ? S.dDir[bex * S.lddir + r] : S.dDir[(long)r * N + nc];
+                }
+                raw[8 * hb + t] = v;
+            }
+        }
+    }
+    const unsigned w4[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+    for (int hb = 0; hb < HBT; ++hb)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            // rows of the two lane halves: 16 hb + t and 16 hb + 8 + t; their words sit in lanes (row >> 2), component row & 3
+            const int ha = 16 * hb + t, hbr = 16 * hb + 8 + t;
+            const unsigned wa = (unsigned)__builtin_amdgcn_readlane((int)w4[ha & 3], ha >> 2);
+            const unsigned wb = (unsigned)__builtin_amdgcn_readlane((int)w4[hbr & 3], hbr >> 2);
+            const unsigned w = hh ? wb : wa;
+            const int h = 16 * hb + 8 * hh + t;
+            const bool keep = h < H && (!S.mask || ((w >> c) & 1u));
+            raw[8 * hb + t] = keep ? raw[8 * hb + t] : 0.f;
+        }
+}
+
 // max_i |col[i * N]| over rows i = first, first + 2, ... < rows: 16 unconditional loads in flight per round trip
 // (rows past the end are clamped to a row of the set: harmless for a maximum; more in flight costs the MT = 8
 // kernels registers they do not have).  A loop with a few loads per iteration pays an L2 round trip per iteration.
@@ -419,7 +496,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
                 mw = lane == frag_row(r, 0) ? (unsigned)bits : mw;
                 mw = lane == frag_row(r, 0) + 4 ? (unsigned)(bits >> 32) : mw;
             }
-            if (lane < 32 && base + lane < H && wcol < N) E.mask[(long)(base + lane) * E.mask_ld + (wcol >> 5)] = mw;
+            // transposed layout: the words of one 32-column chunk are contiguous over the rows (this store is 128 B per
+            // tile, and the dX kernel picks up a chunk's words of 256 rows with one 16-byte load per lane)
+            if (lane < 32 && base + lane < H && wcol < N) E.mask[(wcol >> 5) * E.mask_ld + base + lane] = mw;
         }
         // ---- direct-connect sums: over the D lanes of an example, log2(D) DPP steps (row_shr 1, 2, 4, 8 inside a row of 16
         // lanes; fixed order); the lane with an example's last column holds its sum.  Registers 4g .. 4g+3 are four

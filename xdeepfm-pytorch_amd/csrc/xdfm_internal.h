@@ -164,8 +164,9 @@ struct X3Geom {
 //              those rows are consumed right here by
 //   res        res[b * ldres + res_off + row - dir0] = sum_d out[row][b * D + d] for rows >= dir0 (interaction.py:245-246),
 //              D = 1 << logD in {4, 8, 16}: a D-lane segment sum in the accumulator layout (lane = column), and
-//   mask       bit (n & 31) of mask[row * mask_ld + (n >> 5)] = out[row][n] > 0: all the backward needs of a ReLU level's
-//              saved output once x_prev is saved apart (1 bit instead of 4 bytes per element, written and read).
+//   mask       bit (n & 31) of mask[(n >> 5) * mask_ld + row] = out[row][n] > 0 (mask_ld >= H, a multiple of 4): all the
+//              backward needs of a ReLU level's saved output once x_prev is saved apart (1 bit instead of 4 bytes per
+//              element, written and read).
 struct X3FwdEpi {
     int keep_rows;
     float* res; long ldres; int res_off, dir0, logD;
@@ -191,15 +192,28 @@ struct X3BwxGeom {
     int HBT, HBS, IB;     // h-blocks (of 16) in total / per ring stage, i-blocks (of 32)
     long NT;              // tiles = IB * m
 };
+// Where the dX kernels take dOut from.  dOut != nullptr: the materialised [H][N] tensor.  Otherwise they FORM it in their
+// prologue, exactly as cin_dout does (cin_bwd.hip) -- dOut[h][n] = relu'(out[h][n]) * (dHid[h][n] + direct-connect gradient) --
+// from the gradient of the next level's x_prev, the pooled gradient and the sign bits the forward left (X3FwdEpi.mask,
+// transposed layout): the fp32 dOut (67 MB at level 0 of config 2) is then neither written by xdfm_cin_bwd_prep nor read
+// here.  Rows are those of the level: this launch covers rows [h0, h0 + H).
+struct X3DoutSrc {
+    const float* dOut;
+    const unsigned* mask; long mask_ld;                  // nullptr: linear activation
+    const float* dHid; int hid_rows;                     // rows [0, hid_rows) of the level
+    const float* dDir; int dir_mode; long lddir; int dir_off, dir0, dir_rows, logD;
+    int h0;
+};
+static inline X3DoutSrc x3_dout_plain(const float* dOut) { return X3DoutSrc{dOut, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, 0, 0, 0}; }
 X3BwxGeom x3_bwx_geom(int H, int Hp, int m);
 bool x3_bwx_usable(int H, int Hp, int m);
 size_t x3_bwx_pack_elems(int H, int Hp, int m);
 int x3_bwx_pack(const float* W, int H, int Hp, int m, float* pack, hipStream_t st);
-int x3_level_bwd_x(const float* dOut, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
+int x3_level_bwd_x(const X3DoutSrc& S, const float* xp, const float* x0, const float* pack, int H, int Hp, int m, long N,
                    float* dxp, float* dx0, int flags, hipStream_t st);
 
 // level 0 with folded weights (cin_x3_bwx_sym.hip): the whole gradient goes to dx0, dxp is zero-filled if it is to be set
-int x3_level_bwd_x_sym(const float* dOut, const float* x0, const float* pack, int H, int m, long N, int HBT, int nt,
+int x3_level_bwd_x_sym(const X3DoutSrc& S, const float* x0, const float* pack, int H, int m, long N, int HBT, int nt,
                        float* dxp, float* dx0, int flags, hipStream_t st);
 
 // ---- dW geometry (cin_bwd.hip, cin_x3_bww.hip) ---------------------------------------------------

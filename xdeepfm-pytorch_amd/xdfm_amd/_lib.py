@@ -46,6 +46,9 @@ SIGNATURES = {
     "xdfm_cin_level_fwd_ex_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "xdfm_cin_level_fwd_ex": (c_int, [P, P, P, P, c_int, c_int, c_int, c_long, c_int, P, c_int, P, c_long, c_int, c_int, c_int,
                                       P, c_long, P]),
+    "xdfm_cin_bwd_nodout_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "xdfm_cin_level_bwd_x_src": (c_int, [P, c_long, P, c_int, P, c_int, c_long, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int,
+                                         c_int, c_long, P, P, c_int, P]),
     "xdfm_cin_level_bwd_w_prepared": (c_int, [P, P, P, c_int, c_int, c_int, c_long, P, P, P]),
     "xdfm_cin_bwd_pack_elems": (c_size_t, [c_int, c_int, c_int]),
     "xdfm_cin_bwd_pack": (c_int, [P, c_int, c_int, c_int, P, P]),

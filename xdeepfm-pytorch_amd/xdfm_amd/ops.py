@@ -389,7 +389,7 @@ class CINStack(torch.autograd.Function):
             all(lib.xdfm_cin_level_fwd_ex_supported(H, Hp, m, D) for (H, Hp, *_r) in levels)
         need_bwd = any(ctx.needs_input_grad)
         masks = []
-        mask_ld = (N + 31) // 32
+        mask_chunks = (N + 31) // 32
         for l, (H, Hp, hid, dir0, drows, off) in enumerate(levels):
             W, bias = params[2 * l], params[2 * l + 1]
             W2 = W2s[l]
@@ -400,7 +400,8 @@ class CINStack(torch.autograd.Function):
             bias_c = bias.contiguous()
             if lean:
                 A = torch.empty((hid, N), dtype=torch.float32, device=dev) if hid > 0 else None
-                mk = torch.empty((H, mask_ld), dtype=torch.int32, device=dev) if need_bwd else None
+                mask_ld = (H + 3) // 4 * 4
+                mk = torch.empty((mask_chunks, mask_ld), dtype=torch.int32, device=dev) if need_bwd else None    # [chunk][row]
                 _lib.check(_run("cin_level_fwd", 2.0 * H * Hp * m * N, lambda: lib.xdfm_cin_level_fwd_ex(
                     _ptr(xp), _ptr(x0), _ptr(wf), _ptr(bias_c), H, Hp, m, N, act, _ptr(A), hid, _ptr(result), fm, off, dir0, D,
                     _ptr(mk), mask_ld, _stream())), "cin_level_fwd")
@@ -450,10 +451,14 @@ class CINStack(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             H, Hp, hid, dir0, drows, off = levels[l]
             A = None if ctx.lean else outs[l]
-            mk = masks[l] if ctx.lean else None
             xp = x0 if l == 0 else outs[l - 1][:levels[l - 1][2]]
             W, bias = params[2 * l], params[2 * l + 1]
-            dOut = torch.empty((H, N), dtype=torch.float32, device=dev)
+            mk = masks[l] if ctx.lean else None
+            # lean levels with f16x3 / bf16 dW and dX kernels: dOut is never materialised in fp32 -- the dW kernel takes its
+            # fp16 planes, the dX kernel forms its operand from dOut's sources (sign bits, dhid, pooled gradient) itself
+            no_dout = mk is not None and bool(lib.xdfm_cin_bwd_nodout_supported(H, Hp, m, B, D)) and \
+                os.environ.get("XDFM_CIN_NODOUT", "1") != "0"
+            dOut = None if no_dout else torch.empty((H, N), dtype=torch.float32, device=dev)
             dbias = dbias_all[dbias_off[l]:dbias_off[l] + H]
             has_hid = dhid is not None and hid > 0
             need_dw = ctx.needs_input_grad[7 + 2 * l]
@@ -463,7 +468,7 @@ class CINStack(torch.autograd.Function):
             ws = torch.empty(lib.xdfm_cin_bwd_w_ws_elems(H, Hp, m, N), dtype=torch.float32, device=dev) if need_dw else None
             prepared = ctypes.c_int(0)
             _lib.check(_run("cin_dout", 0.0, lambda: lib.xdfm_cin_bwd_prep(
-                _ptr(A), _ptr(mk), (N + 31) // 32, H, B, D, act, _ptr(dhid) if has_hid else None, 0, hid if has_hid else 0, _ptr(g),
+                _ptr(A), _ptr(mk), mk.shape[1] if mk is not None else 0, H, B, D, act, _ptr(dhid) if has_hid else None, 0, hid if has_hid else 0, _ptr(g),
                 0 if pool == "sum" else 1, fm if pool == "sum" else N, off, dir0, drows, _ptr(dOut), _ptr(dbias), _ptr(dws),
                 _ptr(xp), _ptr(x0), Hp, m, _ptr(ws), ctypes.byref(prepared), _stream())), "cin_dout")
             if need_dw:
@@ -505,11 +510,17 @@ class CINStack(torch.autograd.Function):
                     wz = torch.empty(lib.xdfm_cin_bwd_pack_elems(hc, Hp, m), dtype=torch.float32, device=dev)
                     wc = W2[h0:h0 + hc].contiguous()
                     _lib.check(lib.xdfm_cin_bwd_pack(_ptr(wc), hc, Hp, m, _ptr(wz), _stream()), "cin_bwd_pack")
-                dOc = dOut[h0:h0 + hc]
                 flags = (1 if h0 == 0 else 0) | (0 if dx0_set else 2)     # XDFM_BWX_SET_DXP | XDFM_BWX_SET_DX0
-                _lib.check(_run("cin_level_bwd_x", 2.0 * hc * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_x_ex(
-                    _ptr(dOc), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m, N, _ptr(dxp), _ptr(dx0), flags, _stream())),
-                    "cin_level_bwd_x")
+                if no_dout:
+                    _lib.check(_run("cin_level_bwd_x", 2.0 * hc * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_x_src(
+                        _ptr(mk) if act == 1 else None, mk.shape[1], _ptr(dhid) if has_hid else None, hid if has_hid else 0, _ptr(g),
+                        0 if pool == "sum" else 1, fm if pool == "sum" else N, off, dir0, drows, D, h0, _ptr(xp), _ptr(x0), _ptr(wz),
+                        hc, Hp, m, N, _ptr(dxp), _ptr(dx0), flags, _stream())), "cin_level_bwd_x")
+                else:
+                    dOc = dOut[h0:h0 + hc]
+                    _lib.check(_run("cin_level_bwd_x", 2.0 * hc * Hp * m * N, lambda: lib.xdfm_cin_level_bwd_x_ex(
+                        _ptr(dOc), _ptr(xp), _ptr(x0), _ptr(wz), hc, Hp, m, N, _ptr(dxp), _ptr(dx0), flags, _stream())),
+                        "cin_level_bwd_x")
                 dx0_set = True
             if l == 0 and not all(lib.xdfm_cin_bwd_x_is_folded(min(hstep, H - h0), Hp, m, 1) for h0 in range(0, H, hstep)):
                 dx0 += dxp                               # x_prev of level 0 is x0 itself (the folded dX kernel has put the
