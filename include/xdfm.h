@@ -176,7 +176,7 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
                        int H, int Hp, int m, long N, int act, float* out, void* stream);
 
 /* The forward of a level with what the CIN does with its output fused into the kernel's epilogue (f16x3 / bf16 arithmetic,
- * D in {4, 8, 16}: xdfm_cin_level_fwd_ex_supported): rows [0, keep_rows) are stored to out [keep_rows][N]; rows >= dir0 are
+ * D in {4, 8, 16, 32}: xdfm_cin_level_fwd_ex_supported): rows [0, keep_rows) are stored to out [keep_rows][N]; rows >= dir0 are
  * summed over the embedding axis into res (res[b * ldres + res_off + row - dir0], interaction.py:245-246: the
  * direct-connect half of a level in sum pooling is never written out), res == NULL: no sums; mask != NULL: bit n & 31 of
  * mask[(n >> 5) * mask_ld + row] = out[row][n] > 0 for every row (mask_ld >= H, a multiple of 4; mask 16-byte aligned: all

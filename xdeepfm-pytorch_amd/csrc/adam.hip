@@ -92,8 +92,16 @@ __global__ __launch_bounds__(ADAM_THREADS, 3) void adam_step_kernel(
     __shared__ float bcs[2];
     if (threadIdx.x == 0) {
         const double step = (double)*d.step;
-        bcs[0] = (float)(lr / (1.0 - pow(beta1, step)));
-        bcs[1] = (float)sqrt(1.0 - pow(beta2, step));
+        // with a clock, adam_tick has just written this step's two constants (same formula, same doubles): take them from
+        // its table when the tensor's own step counter agrees with the clock -- two double pow() cost microseconds
+        const int t = clock ? clock[0] : 0;
+        if (clock && step == (double)(clock[1] + t)) {
+            bcs[0] = consts[ADAM_CONSTS_PER_STEP * t];
+            bcs[1] = consts[ADAM_CONSTS_PER_STEP * t + 1];
+        } else {
+            bcs[0] = (float)(lr / (1.0 - pow(beta1, step)));
+            bcs[1] = (float)sqrt(1.0 - pow(beta2, step));
+        }
     }
     __syncthreads();
     const float step_size = bcs[0], bc2_sqrt = bcs[1];
@@ -378,6 +386,15 @@ struct AdamRowsDev {
     float* const* p; float* const* m; float* const* v; unsigned char* const* last; const float* l2;
     float* const* g; unsigned char* const* marks;
 };
+// the embedding or the linear tables' pointer arrays, picked field by field (a reference chosen at run time between the
+// two kernel-argument structs makes hipcc copy both to scratch and index them there: 120 bytes of private memory per lane)
+__device__ __forceinline__ AdamRowsDev adam_rows_pick(bool is_lin, const AdamRowsDev& emb, const AdamRowsDev& lin) {
+    AdamRowsDev R;
+    R.p = is_lin ? lin.p : emb.p; R.m = is_lin ? lin.m : emb.m; R.v = is_lin ? lin.v : emb.v;
+    R.last = is_lin ? lin.last : emb.last; R.l2 = is_lin ? lin.l2 : emb.l2;
+    R.g = is_lin ? lin.g : emb.g; R.marks = is_lin ? lin.marks : emb.marks;
+    return R;
+}
 
 // The chunk of thread idx -- (example, field, chunk of the row) -- and its claim: `old` >= 0 when this thread is the first
 // to reach the chunk in this launch (CAS on the word that holds its `last` byte) and has to bring it from step `old` to t;
@@ -395,7 +412,7 @@ __device__ __forceinline__ AdamClaim adam_claim_chunk(long idx, const float* __r
     long id = (long)X[b * ldx + cols[k.f]];             // as the gather (embed.hip): truncation, clamped
     if (id < 0 || id >= V) id = id < 0 ? 0 : V - 1;
     k.is_lin = q >= QE;
-    const AdamRowsDev& R = k.is_lin ? lin : emb;
+    const AdamRowsDev R = adam_rows_pick(k.is_lin, emb, lin);
     const long w = k.is_lin ? 1 : D;
     const long c0 = id * w / 4, c1 = (id * w + w - 1) / 4;
     k.cc = c0 + (k.is_lin ? 0 : q);
@@ -436,7 +453,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_catchup_rows_kernel(
     k.old = -1; k.f = 0; k.cc = 0; k.is_lin = false;
     if (t > 0 && idx < (long)B * m * QT) k = adam_claim_chunk(idx, X, ldx, cols, vocab, m, D, QE, QT, emb, lin, t, false);
     const bool act = k.old >= 0;
-    const AdamRowsDev& R = k.is_lin ? lin : emb;
+    const AdamRowsDev R = adam_rows_pick(k.is_lin, emb, lin);
     float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), ma = pa, va = pa;
     float4 *p4 = nullptr, *m4 = nullptr, *v4 = nullptr;
     float l2c = 0.f;
@@ -477,7 +494,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
     if (idx < nrow) k = adam_claim_chunk(idx, X, ldx, cols, vocab, m, D, QE, QT, emb, lin, t, true);
     const bool act = k.old >= 0;
     {
-        const AdamRowsDev& R = k.is_lin ? lin : emb;
+        const AdamRowsDev R = adam_rows_pick(k.is_lin, emb, lin);
         float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), ma = pa, va = pa, ga = pa;
         float4 *p4 = nullptr, *m4 = nullptr, *v4 = nullptr;
         float l2c = 0.f;
@@ -511,7 +528,7 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_apply_rows_kernel(
         const int f = (int)((u >> 2) % m);
         const bool is_lin = (u >> 2) >= m;
         if (!is_lin || has_lin) {
-            const AdamRowsDev& R = is_lin ? lin : emb;
+            const AdamRowsDev R = adam_rows_pick(is_lin, emb, lin);
             const long numel = (long)vocab[f] * (is_lin ? 1 : D);
             const long e = numel / 4 * 4 + kk;
             if (e < numel && R.p[f] != nullptr) {

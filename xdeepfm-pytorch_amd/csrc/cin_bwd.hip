@@ -931,7 +931,7 @@ int xdfm_cin_bwd_prep(const float* A, const unsigned* mask, long mask_ld, int H,
 
 int xdfm_cin_bwd_nodout_supported(int H, int Hp, int m, int B, int D) {
     const long N = (long)B * D;
-    return (H > 0 && Hp > 0 && m > 0 && B > 0 && (D == 4 || D == 8 || D == 16) && x3_terms() != 0 && bww_mt(H) == 4 && N % 4 == 0 &&
+    return (H > 0 && Hp > 0 && m > 0 && B > 0 && (D == 4 || D == 8 || D == 16 || D == 32) && x3_terms() != 0 && bww_mt(H) == 4 && N % 4 == 0 &&
             N >= 32 && x3_bwx_usable(H < 256 ? H : 256, Hp, m) && (H <= 256 || H % 256 == 0 || x3_bwx_usable(H % 256, Hp, m)) &&
             H <= (1 << 16)) ? 1 : 0;
 }
@@ -944,7 +944,7 @@ int xdfm_cin_level_bwd_x_src(const unsigned* mask, long mask_ld, const float* dH
     XDFM_REQUIRE(H > 0 && H <= 256 && Hp > 0 && m > 0 && N > 0 && h0 >= 0 && h0 % 4 == 0, "cin_level_bwd_x_src: bad shape H=%d (<=256) Hp=%d m=%d h0=%d",
                  H, Hp, m, h0);
     XDFM_REQUIRE(x3_bwx_usable(H, Hp, m), "cin_level_bwd_x_src: no f16x3 / bf16 dX kernel for H=%d", H);
-    XDFM_REQUIRE(D == 4 || D == 8 || D == 16, "cin_level_bwd_x_src: D=%d", D);
+    XDFM_REQUIRE(D == 4 || D == 8 || D == 16 || D == 32, "cin_level_bwd_x_src: D=%d", D);
     XDFM_REQUIRE(!mask || (mask_ld >= h0 + H && mask_ld % 4 == 0 && (((size_t)mask) & 15) == 0), "cin_level_bwd_x_src: mask pitch %ld", mask_ld);
     XDFM_REQUIRE(dir_mode == 0 || dir_mode == 1, "cin_level_bwd_x_src: dir_mode %d", dir_mode);
     int logD = 0;

@@ -470,7 +470,7 @@ int xdfm_cin_level_fwd(const float* xp, const float* x0, const float* Wf, const 
 }
 
 int xdfm_cin_level_fwd_ex_supported(int H, int Hp, int m, int D) {
-    return (H > 0 && Hp > 0 && m > 0 && (D == 4 || D == 8 || D == 16) && x3_fwd_usable(H, Hp, m)) ? 1 : 0;
+    return (H > 0 && Hp > 0 && m > 0 && (D == 4 || D == 8 || D == 16 || D == 32) && x3_fwd_usable(H, Hp, m)) ? 1 : 0;
 }
 
 int xdfm_cin_level_fwd_ex(const float* xp, const float* x0, const float* Wf, const float* bias, int H, int Hp, int m, long N,

@@ -516,6 +516,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void cin_fwd_x3_kernel(
                     t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x112, 0xf, 0xf, true));
                     if (E.logD > 2) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x114, 0xf, 0xf, true));
                     if (E.logD > 3) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x118, 0xf, 0xf, true));
+                    // D = 32: lane 15's sum of the first 16 columns joins lane 31's (row_bcast:15 into rows 1 and 3)
+                    if (E.logD > 4) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x142, 0xa, 0xf, true));
                     s4[q] = t;
                 }
                 float* dst = res_t + 8 * g4 + res_lane;                           // rows base + 8 g4 + 4 hh .. + 3

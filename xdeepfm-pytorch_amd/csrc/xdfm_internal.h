@@ -163,7 +163,7 @@ struct X3Geom {
 //              stores its hidden half (the next level's x_prev) and, in sum pooling, nothing of its direct-connect half:
 //              those rows are consumed right here by
 //   res        res[b * ldres + res_off + row - dir0] = sum_d out[row][b * D + d] for rows >= dir0 (interaction.py:245-246),
-//              D = 1 << logD in {4, 8, 16}: a D-lane segment sum in the accumulator layout (lane = column), and
+//              D = 1 << logD in {4, 8, 16, 32}: a D-lane segment sum in the accumulator layout (lane = column), and
 //   mask       bit (n & 31) of mask[(n >> 5) * mask_ld + row] = out[row][n] > 0 (mask_ld >= H, a multiple of 4): all the
 //              backward needs of a ReLU level's saved output once x_prev is saved apart (1 bit instead of 4 bytes per
 //              element, written and read).

@@ -381,7 +381,7 @@ class CINStack(torch.autograd.Function):
             _lib.check(lib.xdfm_cin_pack_all(ctypes.cast(jobs, ctypes.c_void_p), len(levels), _stream()), "cin_pack_all")
             if not need_bwd:
                 wzs = None
-        # "lean" levels (sum pooling, f16x3 / bf16 forward, D in {4, 8, 16}): the forward's epilogue sums the direct-connect
+        # "lean" levels (sum pooling, f16x3 / bf16 forward, D in {4, 8, 16, 32}): the forward's epilogue sums the direct-connect
         # rows into `result` and leaves the ReLU sign bits, so only the hidden rows (the next level's x_prev) are ever
         # written -- no direct_sum launches, no direct-connect half in memory, and the backward reads 1 bit per element
         # instead of the saved output (xdfm_cin_level_fwd_ex / xdfm_cin_bwd_prep)
