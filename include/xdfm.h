@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define XDFM_ABI_VERSION 7
+#define XDFM_ABI_VERSION 8
 
 enum {
     XDFM_OK = 0,
@@ -481,6 +481,45 @@ int xdfm_adam_selftest(int mode, unsigned long long n, unsigned long long seed, 
  * in place. */
 int xdfm_vocab_lse_update(const float* z, long ld, int rows, int T, float* m, float* s, void* stream);
 int xdfm_vocab_softmax_grad(float* z, long ld, int rows, int T, const float* lse, const float* g, void* stream);
+
+/* The same cross-entropy without the logits in HBM (csrc/vocab_ce_x3.hip), for ALL sparse fields' heads over the same
+ * hidden rows in one launch per pass: for heads of width K = 32 or 64 a 32 x 32 block of logits lives only in the
+ * accumulators of one wave (f16x3 products: hi*hi + hi*lo + lo*hi on fp16 halves of power-of-two scaled operands, fp32
+ * accumulation, base-2 exp / log).  Replaces, per sparse field, nn.Linear(K, V) + F.cross_entropy(reduction='none')
+ * (deepctr/xdeepfm_pro/sfg_decoder.py:146-149, :277-283) and their autograd backward.  No float atomics: partial
+ * results are merged in a fixed order, every row of dW / db is written once.
+ *   supported       1 when K is handled and the f16x3 arithmetic is selected (option cin_math == 1), else 0: callers
+ *                   then use the tiled path above.
+ *   plan            host-side: fills V, vr, item0, blk0, ws_off of fields[0..F) (W, bias, dW, db are the caller's) and
+ *                   the work items of the rows-stationary kernels (pass items == NULL to count); returns the number of
+ *                   items, *ws_elems = floats of scratch, *n_blk = 128-row weight blocks of all fields.  The caller
+ *                   copies both tables to the device.
+ *   pack_hidden     hidden [R][K] fp32, contiguous -> `pack` (pack_elems(R, K) floats): MFMA fragments of H and H^T,
+ *                   hi / lo halves, one power-of-two scale.  Once per step: every field's head reads the same rows.
+ *   fwd             ce[f][r] = logsumexp_v(h_r.W_v + b_v) - (h_r.W_t + b_t), t = targets[f][r] (int64, clamped to
+ *                   [0, V_f)); lse2 [F][rows_padded(R)] (zeroed by the caller) receives the base-2 log-sum-exp and
+ *                   wmax [F] the bits of max|W_f|: both are inputs of the backward.
+ *   pack_g          upstream gradients g [F][R] -> gpack (F * (4 + rows_padded(R)) floats): g scaled to fp16 range.
+ *   bwd_h           dh[r][:] = sum_f [ sum_v g[f][r] softmax_f[r][v] W_f[v][:] - g[f][r] W_f[t][:] ]
+ *   bwd_w           fields[f].dW [V_f][K], fields[f].db [V_f] = (g (softmax - onehot(target)))^T H, column sums
+ *                   (either pointer may be NULL). */
+typedef struct { const float* W; const float* bias; float* dW; float* db; long ws_off; int V, vr, item0, blk0; } xdfm_vce_field;
+typedef struct { int field, sb0, sb1, range; } xdfm_vce_item;
+int xdfm_vocab_ce_x3_supported(int K);
+long xdfm_vocab_ce_pack_elems(int R, int K);
+long xdfm_vocab_ce_rows_padded(int R);
+long xdfm_vocab_ce_plan(int F, const int* V, int R, int K, xdfm_vce_field* fields, xdfm_vce_item* items, long max_items,
+                        long* ws_elems, int* n_blk);
+int xdfm_vocab_ce_pack_hidden(const float* hidden, long ldh, int R, int K, float* pack, void* stream);
+int xdfm_vocab_ce_fwd(const float* pack, const float* hidden, long ldh, int R, int K, const xdfm_vce_field* fields, int F,
+                      const xdfm_vce_item* items, long n_items, const long* targets, float* ws, float* ce, float* lse2,
+                      unsigned* wmax, void* stream);
+int xdfm_vocab_ce_pack_g(const float* g, int F, int R, float* gpack, void* stream);
+int xdfm_vocab_ce_bwd_h(const float* pack, int R, int K, const xdfm_vce_field* fields, int F, const xdfm_vce_item* items, long n_items,
+                        const long* targets, const float* g, const float* gpack, const float* lse2, unsigned* wmax, float* ws,
+                        float* dh, long lddh, void* stream);
+int xdfm_vocab_ce_bwd_w(const float* pack, int R, int K, const xdfm_vce_field* fields, int F, int n_blk, const long* targets,
+                        const float* gpack, const float* lse2, const unsigned* wmax, void* stream);
 
 #ifdef __cplusplus
 }

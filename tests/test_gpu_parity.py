@@ -71,7 +71,7 @@ def cin_math(request):
 def test_native_library_is_loaded():
     from xdfm_amd import _lib
     lib = _lib.load()
-    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 7
+    assert lib.xdfm_abi_version() == _lib.ABI_VERSION == 8
     assert lib.xdfm_device_count() >= 1
     with open("/proc/self/maps") as f:
         assert "libxdfm_hip.so" in f.read()

@@ -133,3 +133,44 @@ def test_vocab_softmax_ce_tiles_vs_materialised_logits(rows, K, V, tile_bytes):
     for got, w, name in ((h.grad, h64.grad, "dh"), (W.grad, W64.grad, "dW"), (b.grad, b64.grad, "db")):
         w = w.cpu().numpy()
         np.testing.assert_allclose(got.cpu().numpy(), w, rtol=2e-4, atol=2e-5 * float(np.abs(w).max()), err_msg=name)
+
+
+@pytest.mark.parametrize("rows,K,vocabs", [(300, 64, (50000, 77, 1000)), (17, 32, (1000, 33)), (1, 64, (5,)),
+                                           (1100, 64, (70001, 256)), (513, 32, (4097,))])
+def test_vocab_heads_ce_fused_vs_materialised_logits(rows, K, vocabs):
+    """ops.VocabHeadsCE (csrc/vocab_ce_x3.hip): the heads of all sparse fields over the same hidden rows with the logits
+    only in MFMA accumulators (sfg_decoder.py:146-149 + :277-283) -- losses and all gradients against the materialised
+    computation in float64; ragged row counts (tiles of 32, row groups of 512), vocabularies that are no multiple of the
+    256-row stages, a second row group (1100 rows), one-row / one-entry edge cases.  Tolerances: the f16x3 products carry
+    ~2^-22 relative error per term, the base-2 exp / log ~1 ulp; same bars as the tiled path's test above."""
+    from xdfm_amd import ops
+    dev = _dev()
+    assert ops.vocab_heads_ce_supported(K) and not ops.vocab_heads_ce_supported(48)
+    g = torch.Generator().manual_seed(rows + sum(vocabs))
+    h = torch.randn(rows, K, generator=g).to(dev).requires_grad_(True)
+    Ws = [(torch.randn(V, K, generator=g) * 0.3).to(dev).requires_grad_(True) for V in vocabs]
+    bs = [(torch.randn(V, generator=g) * 0.3).to(dev).requires_grad_(True) for V in vocabs]
+    tgt = torch.stack([torch.randint(0, V, (rows,), generator=g) for V in vocabs]).to(dev)
+    gout = (torch.rand(len(vocabs), rows, generator=g) * 1e-3).to(dev)
+    ce = ops.vocab_heads_ce(h, tgt, Ws, bs)
+    (ce * gout).sum().backward()
+    h64 = h.detach().double().requires_grad_(True)
+    W64 = [w.detach().double().requires_grad_(True) for w in Ws]
+    b64 = [b.detach().double().requires_grad_(True) for b in bs]
+    want = torch.stack([torch.nn.functional.cross_entropy(torch.nn.functional.linear(h64, w, b), tgt[f], reduction="none")
+                        for f, (w, b) in enumerate(zip(W64, b64))])
+    (want * gout.double()).sum().backward()
+    np.testing.assert_allclose(ce.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=2e-5, atol=2e-5)
+    pairs = [(h.grad, h64.grad, "dh")] + [(w.grad, w6.grad, "dW%d" % f) for f, (w, w6) in enumerate(zip(Ws, W64))] + \
+            [(b.grad, b6.grad, "db%d" % f) for f, (b, b6) in enumerate(zip(bs, b64))]
+    for got, w, name in pairs:
+        w = w.cpu().numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), w, rtol=2e-4, atol=2e-5 * float(np.abs(w).max()), err_msg=name)
+    # determinism: fixed summation orders, no atomics on floats
+    h2 = h.detach().clone().requires_grad_(True)
+    W2 = [w.detach().clone().requires_grad_(True) for w in Ws]
+    b2 = [b.detach().clone().requires_grad_(True) for b in bs]
+    ce2 = ops.vocab_heads_ce(h2, tgt, W2, b2)
+    (ce2 * gout).sum().backward()
+    assert torch.equal(ce2, ce) and torch.equal(h2.grad, h.grad)
+    assert all(torch.equal(a.grad, b_.grad) for a, b_ in zip(W2, Ws))

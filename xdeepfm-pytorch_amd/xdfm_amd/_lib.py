@@ -78,6 +78,15 @@ SIGNATURES = {
     "xdfm_adam_selftest": (c_int, [c_int, ctypes.c_ulonglong, ctypes.c_ulonglong, c_double, c_double, c_double, c_double, P, P]),
     "xdfm_vocab_lse_update": (c_int, [P, c_long, c_int, c_int, P, P, P]),
     "xdfm_vocab_softmax_grad": (c_int, [P, c_long, c_int, c_int, P, P, P]),
+    "xdfm_vocab_ce_x3_supported": (c_int, [c_int]),
+    "xdfm_vocab_ce_pack_elems": (c_long, [c_int, c_int]),
+    "xdfm_vocab_ce_rows_padded": (c_long, [c_int]),
+    "xdfm_vocab_ce_plan": (c_long, [c_int, P, c_int, c_int, P, P, c_long, P, P]),
+    "xdfm_vocab_ce_pack_hidden": (c_int, [P, c_long, c_int, c_int, P, P]),
+    "xdfm_vocab_ce_fwd": (c_int, [P, P, c_long, c_int, c_int, P, c_int, P, c_long, P, P, P, P, P, P]),
+    "xdfm_vocab_ce_pack_g": (c_int, [P, c_int, c_int, P, P]),
+    "xdfm_vocab_ce_bwd_h": (c_int, [P, c_int, c_int, P, c_int, P, c_long, P, P, P, P, P, P, P, c_long, P]),
+    "xdfm_vocab_ce_bwd_w": (c_int, [P, c_int, c_int, P, c_int, c_int, P, P, P, P, P]),
     "xdfm_colsum_ws_elems": (c_size_t, [c_int]),
     "xdfm_colsum": (c_int, [P, c_long, c_int, c_long, P, P, P]),
     "xdfm_relu_bwd_colsum": (c_int, [P, P, c_long, c_int, c_long, c_long, P, P, P, P]),
@@ -108,7 +117,7 @@ class AdamRows(ctypes.Structure):
                 ("grad", c_void_p), ("marks", c_void_p)]
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _lib = None
 
 

@@ -6,6 +6,8 @@ All ops require float32 CUDA (ROCm) tensors and raise otherwise -- there is no C
 """
 import ctypes
 import os
+
+import numpy as np
 from typing import List, Optional, Sequence
 
 import torch
@@ -833,6 +835,117 @@ class VocabSoftmaxCE(torch.autograd.Function):
 def vocab_softmax_ce(hidden, W, b, target):
     _need_cuda(hidden, "decoder hidden layer")
     return VocabSoftmaxCE.apply(hidden, W, b, target)
+
+
+_VCE_FIELD = np.dtype([("W", "u8"), ("bias", "u8"), ("dW", "u8"), ("db", "u8"), ("ws_off", "i8"), ("V", "i4"), ("vr", "i4"),
+                       ("item0", "i4"), ("blk0", "i4")])            # xdfm_vce_field (include/xdfm.h)
+_VCE_ITEM = np.dtype([("field", "i4"), ("sb0", "i4"), ("sb1", "i4"), ("range", "i4")])      # xdfm_vce_item
+_VCE_PLANS = {}
+
+
+def _vce_plan(R, K, vocabs, dev):
+    """Host tables of xdfm_vocab_ce_plan for (R, K, vocabularies) + the items on the device (they hold no pointers)."""
+    key = (R, K, tuple(vocabs), dev)
+    plan = _VCE_PLANS.get(key)
+    if plan is None:
+        lib = _lib.load()
+        V = np.asarray(vocabs, dtype=np.int32)
+        fields = np.zeros(len(vocabs), dtype=_VCE_FIELD)
+        ws, nblk = ctypes.c_long(0), ctypes.c_int(0)
+        n = lib.xdfm_vocab_ce_plan(len(vocabs), V.ctypes.data, R, K, fields.ctypes.data, None, 0, ctypes.byref(ws), ctypes.byref(nblk))
+        if n <= 0:
+            raise _lib.XdfmError("vocab_ce_plan: " + lib.xdfm_last_error().decode("utf-8", "replace"))
+        items = np.zeros(n, dtype=_VCE_ITEM)
+        lib.xdfm_vocab_ce_plan(len(vocabs), V.ctypes.data, R, K, fields.ctypes.data, items.ctypes.data, n, ctypes.byref(ws),
+                               ctypes.byref(nblk))
+        items_dev = torch.from_numpy(items.view(np.uint8)).to(dev)
+        if len(_VCE_PLANS) > 64:
+            _VCE_PLANS.clear()
+        plan = _VCE_PLANS[key] = (fields, items_dev, int(n), int(ws.value), int(nblk.value))
+    return plan
+
+
+def _vce_fields(plan, Ws, bs, dWs, dbs, dev):
+    fields = plan[0].copy()
+    fields["W"] = [w.data_ptr() for w in Ws]
+    fields["bias"] = [b.data_ptr() for b in bs]
+    fields["dW"] = [0 if t is None else t.data_ptr() for t in dWs]
+    fields["db"] = [0 if t is None else t.data_ptr() for t in dbs]
+    return torch.from_numpy(fields.view(np.uint8)).to(dev)
+
+
+class VocabHeadsCE(torch.autograd.Function):
+    """ce[f][r] of ALL sparse fields' heads over the same hidden rows, logits never in HBM (csrc/vocab_ce_x3.hip; the
+    heads of deepctr/xdeepfm_pro/sfg_decoder.py:146-149 + F.cross_entropy of :277-283).  hidden [R, K] (K = 32 or 64),
+    targets [F, R] int64, then the F weights [V_f, K] and the F biases [V_f].  The hidden layer is packed into MFMA
+    fragments once per pass; all fields share each launch (a table of per-field pointers and work items): log-sum-exp
+    partials + merge in the forward; in the backward the hidden gradient (partial slabs summed in a fixed order) and
+    the weight / bias gradients (every row written once, the target's -g included)."""
+
+    @staticmethod
+    def forward(ctx, hidden, targets, *params):
+        lib = _lib.load()
+        F_ = len(params) // 2
+        Ws, bs = params[:F_], params[F_:]
+        R, K = hidden.shape
+        dev = hidden.device
+        hidden = hidden.contiguous()
+        targets = targets.contiguous()
+        for t in params:
+            if not t.is_contiguous():
+                raise ValueError("xdfm: head parameters must be contiguous")
+        plan = _vce_plan(R, K, [w.shape[0] for w in Ws], dev)
+        fields = _vce_fields(plan, Ws, bs, [None] * F_, [None] * F_, dev)
+        pack = torch.empty(lib.xdfm_vocab_ce_pack_elems(R, K), dtype=torch.float32, device=dev)
+        _lib.check(lib.xdfm_vocab_ce_pack_hidden(_ptr(hidden), K, R, K, _ptr(pack), _stream()), "vocab_ce_pack_hidden")
+        Rpad = lib.xdfm_vocab_ce_rows_padded(R)
+        ce = torch.empty(F_, R, dtype=torch.float32, device=dev)
+        lse2 = torch.zeros(F_, Rpad, dtype=torch.float32, device=dev)
+        wmax = torch.empty(F_, dtype=torch.int32, device=dev)
+        ws = torch.empty(plan[3], dtype=torch.float32, device=dev)
+        _lib.check(lib.xdfm_vocab_ce_fwd(_ptr(pack), _ptr(hidden), K, R, K, _ptr(fields), F_, _ptr(plan[1]), plan[2], _ptr(targets),
+                                         _ptr(ws), _ptr(ce), _ptr(lse2), _ptr(wmax), _stream()), "vocab_ce_fwd")
+        ctx.save_for_backward(hidden, targets, pack, lse2, wmax, *params)
+        ctx.plan = plan
+        return ce
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        hidden, targets, pack, lse2, wmax = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        F_ = len(params) // 2
+        Ws, bs = params[:F_], params[F_:]
+        R, K = hidden.shape
+        dev = hidden.device
+        plan = ctx.plan
+        g = g.contiguous()
+        Rpad = lib.xdfm_vocab_ce_rows_padded(R)
+        gpack = torch.empty(F_ * (4 + Rpad), dtype=torch.float32, device=dev)
+        _lib.check(lib.xdfm_vocab_ce_pack_g(_ptr(g), F_, R, _ptr(gpack), _stream()), "vocab_ce_pack_g")
+        dWs = [torch.empty_like(Ws[f]) if ctx.needs_input_grad[2 + f] else None for f in range(F_)]
+        dbs = [torch.empty_like(bs[f]) if ctx.needs_input_grad[2 + F_ + f] else None for f in range(F_)]
+        fields = _vce_fields(plan, Ws, bs, dWs, dbs, dev)
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty_like(hidden)
+            ws = torch.empty(plan[3], dtype=torch.float32, device=dev)
+            _lib.check(lib.xdfm_vocab_ce_bwd_h(_ptr(pack), R, K, _ptr(fields), F_, _ptr(plan[1]), plan[2], _ptr(targets), _ptr(g),
+                                               _ptr(gpack), _ptr(lse2), _ptr(wmax), _ptr(ws), _ptr(dh), K, _stream()), "vocab_ce_bwd_h")
+        if any(t is not None for t in dWs + dbs):
+            _lib.check(lib.xdfm_vocab_ce_bwd_w(_ptr(pack), R, K, _ptr(fields), F_, plan[4], _ptr(targets), _ptr(gpack), _ptr(lse2),
+                                               _ptr(wmax), _stream()), "vocab_ce_bwd_w")
+        return (dh, None, *dWs, *dbs)
+
+
+def vocab_heads_ce_supported(K: int) -> bool:
+    return bool(_lib.load().xdfm_vocab_ce_x3_supported(int(K)))
+
+
+def vocab_heads_ce(hidden, targets, weights, biases):
+    """[F, R] cross-entropies of F heads (weights[f] [V_f, K], biases[f] [V_f]) over hidden [R, K], targets [F, R] int64."""
+    _need_cuda(hidden, "decoder hidden layer")
+    return VocabHeadsCE.apply(hidden, targets, *weights, *biases)
 
 
 # --------------------------------------------------------------------------------------------- #

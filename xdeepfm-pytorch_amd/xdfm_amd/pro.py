@@ -276,13 +276,25 @@ class BaseModelSFG(BaseModel):
         total_dense = torch.zeros((), device=X.device)
         if x_rows.shape[0] > 0:
             hidden = dec.hidden(d_rows, l_rows)
-            for fc in self.sparse_feature_columns:
-                col = self.feature_index[fc.name][0]
-                head = dec.sparse_heads[fc.name]
-                ce = ops.vocab_softmax_ce(hidden, head.weight, head.bias, x_rows[:, col])
-                masked = ce.sum() / num_positive
-                total_sparse = total_sparse + masked
-                loss_dict['sfg_sparse_%s' % fc.name] = masked
+            fcs = list(self.sparse_feature_columns)
+            if fcs and ops.vocab_heads_ce_supported(hidden.shape[1]):
+                # all heads in one autograd node: the hidden rows are packed once, no logits in HBM (ops.VocabHeadsCE)
+                cols = [self.feature_index[fc.name][0] for fc in fcs]
+                targets = x_rows[:, cols].long().t().contiguous()
+                heads = [dec.sparse_heads[fc.name] for fc in fcs]
+                ce_all = ops.vocab_heads_ce(hidden, targets, [h.weight for h in heads], [h.bias for h in heads])
+                per_field = ce_all.sum(dim=1) / num_positive
+                for k, fc in enumerate(fcs):
+                    total_sparse = total_sparse + per_field[k]
+                    loss_dict['sfg_sparse_%s' % fc.name] = per_field[k]
+            else:
+                for fc in fcs:
+                    col = self.feature_index[fc.name][0]
+                    head = dec.sparse_heads[fc.name]
+                    ce = ops.vocab_softmax_ce(hidden, head.weight, head.bias, x_rows[:, col])
+                    masked = ce.sum() / num_positive
+                    total_sparse = total_sparse + masked
+                    loss_dict['sfg_sparse_%s' % fc.name] = masked
             if dec.dense_head is not None:
                 cols = [c for fc in self.dense_feature_columns for c in range(*self.feature_index[fc.name])]
                 mse = F.mse_loss(dec.dense_head(hidden), x_rows[:, cols], reduction='none').mean(dim=-1)
