@@ -237,39 +237,45 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
         publish(sb);
         __syncthreads();
         if (sb + 1 < sb1) load_w(sb + 1);               // in flight while this stage is consumed
-#pragma unroll 1
-        for (int wb = 0; wb < VX_WAVES; ++wb) {
-            const float cw = VX_LOG2E * invH * Linv[wb];
-            float b2[16];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bq = *reinterpret_cast<const float4*>(Lbias + wb * 32 + 8 * q + 4 * hh);
-                b2[4 * q] = bq.x; b2[4 * q + 1] = bq.y; b2[4 * q + 2] = bq.z; b2[4 * q + 3] = bq.w;
-            }
+        auto zmma = [&](int wb, f32x16 (&acc)[2]) {            // z^T of the stage's block wb against both tiles
             h8 ah[KS], al[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 ah[s] = La[((wb * KS + s) * 2 + 0) * 64 + lane];
                 al[s] = La[((wb * KS + s) * 2 + 1) * 64 + lane];
             }
-            f32x16 acc[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
                     acc[t] = x3_mfma<3>(al[s], bh[t][s], acc[t]);
                     acc[t] = x3_mfma<3>(ah[s], bl[t][s], acc[t]);
                     acc[t] = x3_mfma<3>(ah[s], bh[t][s], acc[t]);
                 }
+        };
+        auto bias_of = [&](int wb, float (&b2)[16]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = *reinterpret_cast<const float4*>(Lbias + wb * 32 + 8 * q + 4 * hh);
+                b2[4 * q] = bq.x; b2[4 * q + 1] = bq.y; b2[4 * q + 2] = bq.z; b2[4 * q + 3] = bq.w;
             }
-            if constexpr (MODE == 0) {
+        };
+        if constexpr (MODE == 0) {
+            // software pipeline inside the wave: the MFMAs of block wb + 1 are issued before the exponentials of block wb
+            f32x16 acc[2][2];
+            auto lse_step = [&](int wb, const f32x16 (&a)[2]) {
+                const float cw = VX_LOG2E * invH * Linv[wb];
+                float b2[16];
+                bias_of(wb, b2);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     float z[16], mx = VX_NEG;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { z[r] = fmaf(acc[t][r], cw, b2[r]); mx = fmaxf(mx, z[r]); }
+                    for (int r = 0; r < 16; ++r) { z[r] = fmaf(a[t][r], cw, b2[r]); mx = fmaxf(mx, z[r]); }
                     const float mn = fmaxf(st_m[t], mx);
                     float sum = 0.f;
 #pragma unroll
@@ -277,7 +283,23 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
                     st_s[t] = fmaf(st_s[t], vx_exp2(st_m[t] - mn), sum);
                     st_m[t] = mn;
                 }
-            } else {
+            };
+            zmma(0, acc[0]);
+#pragma unroll 1
+            for (int wb = 0; wb < VX_WAVES; wb += 2) {
+                zmma(wb + 1, acc[1]);
+                lse_step(wb, acc[0]);
+                if (wb + 2 < VX_WAVES) zmma(wb + 2, acc[0]);
+                lse_step(wb + 1, acc[1]);
+            }
+        } else {
+#pragma unroll 1
+            for (int wb = 0; wb < VX_WAVES; ++wb) {
+                const float cw = VX_LOG2E * invH * Linv[wb];
+                float b2[16];
+                bias_of(wb, b2);
+                f32x16 acc[2];
+                zmma(wb, acc);
                 h8 ph[2][2], pl[2][2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -407,7 +429,7 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
     const float* __restrict__ gpack, const long* __restrict__ tgt_all, int R, long Rpad) {
     constexpr int KS = 2 * KT, K = 32 * KT;
     constexpr int NHF = KS * 2 * 64, NHT = KT * 2 * 2 * 64;            // h8 per tile
-    __shared__ VxTileLds<KT> L[2];
+    __shared__ VxTileLds<KT> L[3];                 // ring: the tile in work, the next one (its z is already being formed), the one arriving
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
     constexpr int PER = (NHF + NHT) / (64 * VX_WS_WAVES);              // h8 per thread and tile (KT = 2: 4)
     static_assert((NHF + NHT) % (64 * VX_WS_WAVES) == 0 && NHF % (64 * VX_WS_WAVES) == 0, "tile split");
@@ -482,11 +504,9 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
         __syncthreads();                                   // the previous block's last tile is consumed
         fetch(0);
         park(0);
+        if (ntiles > 1) { fetch(1); park(1); }
         __syncthreads();
-        for (int t = 0; t < ntiles; ++t) {
-            const int buf = t & 1;
-            if (t + 1 < ntiles) fetch(t + 1);
-            f32x16 z;
+        auto zmma = [&](int buf, f32x16& z) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
 #pragma unroll
@@ -496,6 +516,12 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
                 z = x3_mfma<3>(ah, bl[s], z);
                 z = x3_mfma<3>(ah, bh[s], z);
             }
+        };
+        // one tile: the next tile's z MFMAs are issued first, so that they run under this tile's exponentials
+        auto tile_step = [&](int t, int buf, f32x16& z, f32x16& zn) {
+            const int bufn = buf == 2 ? 0 : buf + 1, bufa = bufn == 2 ? 0 : bufn + 1;
+            if (t + 2 < ntiles) fetch(t + 2);
+            if (t + 1 < ntiles) zmma(bufn, zn);
             h8 ph[2], pl[2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -524,8 +550,19 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
                     acc[kt] = x3_mfma<3>(th, pl[sp], acc[kt]);
                     acc[kt] = x3_mfma<3>(th, ph[sp], acc[kt]);
                 }
-            if (t + 1 < ntiles) park(buf ^ 1);
+            if (t + 2 < ntiles) park(bufa);                // the slot of tile t - 1: every wave left it at the last barrier
             __syncthreads();
+        };
+        f32x16 za, zb;
+        zmma(0, za);
+        int buf = 0;
+        for (int t = 0; t < ntiles; t += 2) {
+            tile_step(t, buf, za, zb);
+            buf = buf == 2 ? 0 : buf + 1;
+            if (t + 1 < ntiles) {
+                tile_step(t + 1, buf, zb, za);
+                buf = buf == 2 ? 0 : buf + 1;
+            }
         }
         const float dbo = dbacc + __shfl_xor(dbacc, 32);
         if (live) {
@@ -571,6 +608,16 @@ long xdfm_vocab_ce_plan(int F, const int* V, int R, int K, xdfm_vce_field* field
     // one workgroup (64-128 KB of LDS) per CU at a time: about four rounds of 256 over all fields and row groups
     long spr = ceil_div(stages * rg, 1024);
     if (spr < 1) spr = 1;
+    for (;; ++spr) {                            // the per-field round-up must not spill into a fifth, nearly empty round
+        long wgs = 0;
+        int longest = 0;
+        for (int f = 0; f < F; ++f) {
+            const int nsb = ceil_div(V[f], VX_SB);
+            wgs += (long)ceil_div(nsb, spr) * rg;
+            longest = nsb > longest ? nsb : longest;
+        }
+        if (wgs <= 1024 || spr >= longest) break;
+    }
     long n = 0, ws = 0;
     int blk = 0;
     for (int f = 0; f < F; ++f) {
