@@ -72,6 +72,10 @@ WORKLOADS = {
     # BASELINE.json configs[4] shape on one GPU: Avazu (22 sparse fields, no dense), emb_dim 32, deep CIN, in the bf16
     # MFMA arithmetic the config names (cin_math 2; --cin-math 1 runs it in f16x3)
     "avazu_c5": dict(n_sparse=22, n_dense=0, emb_dim=32, cin=(512, 256, 256, 128), dnn=(256, 256), batch=4096),
+    # xDeepFMPro = config 2's model + the SFG decoder (one vocabulary-wide softmax head per sparse field over
+    # the positive rows); 1e5 rows per field unless a preset is named
+    "criteo_pro": dict(n_sparse=26, n_dense=13, emb_dim=16, cin=(256, 128, 128), dnn=(256, 256), batch=4096, model="xDeepFMPro",
+                       preset="mid"),
     "criteo_c3_attn": dict(n_sparse=26, n_dense=13, emb_dim=16, cin=(256, 128), dnn=(256, 256), batch=4096,
                            model="xDeepFMAttention"),
 }
@@ -97,7 +101,10 @@ def build_model(cfg, vocab, device, lazy_rows=False):
     from deepctr import models
     cols = [SparseFeat("C%d" % (i + 1), v, cfg["emb_dim"]) for i, v in enumerate(vocab)]
     cols += [DenseFeat("I%d" % (i + 1), 1) for i in range(cfg["n_dense"])]
-    cls = getattr(models, cfg.get("model", "xDeepFM"))
+    if cfg.get("model") == "xDeepFMPro":
+        from deepctr.xdeepfm_pro import xDeepFMPro as cls
+    else:
+        cls = getattr(models, cfg.get("model", "xDeepFM"))
     model = cls(cols, cols, dnn_hidden_units=cfg["dnn"], cin_layer_size=cfg["cin"], l2_reg_dnn=1e-5, device=device)
     if lazy_rows:
         from xdfm_amd.optim import TableAdam
@@ -185,8 +192,8 @@ def pmc_traffic(bracket, workload, math_mode):
     so the figure comes from the committed rocprofv3 --pmc passes over THIS script (tools/profile_round.sh: bench.py with
     eager launches, XDFM_HIP_GRAPH=0 -- counter collection over the graph-replayed step hung in round 1; FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) --
-    profiles/r02_pmc_bench_traffic.json, profiles/r02_pmc_cin.md.  null for any other workload or arithmetic."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_bench_traffic.json")
+    profiles/r03_pmc_bench_traffic.json, profiles/r03_pmc_traffic.md.  null for any other workload or arithmetic."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_bench_traffic.json")
     if workload != "criteo_c2" or math_mode != 1 or bracket not in PMC_KERNEL or not os.path.exists(path):
         return {}
     rows = [v for k, v in json.load(open(path)).items() if k.startswith(PMC_KERNEL[bracket])]
@@ -195,7 +202,7 @@ def pmc_traffic(bracket, workload, math_mode):
         return {}
     total = sum(v["total_bytes"] * v["launches"] for v in rows) / n
     return dict(traffic=round(total), traffic_unit="bytes/launch (2 x FETCH_SIZE + WRITE_SIZE, mean over the levels)",
-                traffic_source="profiles/r02_pmc_cin.md (rocprofv3 --pmc over bench.py, eager launches)")
+                traffic_source="profiles/r03_pmc_traffic.md (rocprofv3 --pmc over bench.py, eager launches)")
 
 
 def main():
@@ -266,7 +273,7 @@ def main():
     B = cfg["batch"]
     if args.cin_math is not None or args.workload == "avazu_c5":
         _lib.set_option("cin_math", args.cin_math if args.cin_math is not None else 2)    # config 5 names the bf16 MFMA path
-    preset = args.vocab_preset or ("criteo-card" if cfg["n_sparse"] == len(CRITEO_CARD) else "mid")
+    preset = args.vocab_preset or cfg.get("preset") or ("criteo-card" if cfg["n_sparse"] == len(CRITEO_CARD) else "mid")
     vocab = [args.vocab] * cfg["n_sparse"] if args.vocab > 0 else preset_vocab(preset, cfg["n_sparse"])
     vocab_name = ("%d rows/field" % args.vocab) if args.vocab > 0 else preset
     dp = xdist.current()
@@ -280,8 +287,8 @@ def main():
     class Run(object):
         """One model + its resident batches; every rank draws its own shard of the global batch (weak scaling)."""
 
-        def __init__(self, vocab, lazy_rows=False, uniform=False):
-            self.model = build_model(cfg, vocab, device, lazy_rows)
+        def __init__(self, vocab, lazy_rows=False, uniform=False, cfg_=None):
+            self.model = build_model(cfg_ or cfg, vocab, device, lazy_rows)
             self.model.train()
             self.n_res = 8
             self.batches = [(torch.from_numpy(X).to(device), torch.from_numpy(y).to(device)) for X, y in
@@ -430,6 +437,16 @@ def main():
                                    else "dense Adam sweep (TableAdam picks it below 64 M table parameters: same bits, faster there)")
         log("mid vocabulary: %.3f ms/step" % (mdt / args.steps * 1e3))
         del mid
+        if args.workload == "criteo_c2":
+            # (1b) SURVEY 8(f2): the same model with the SFG decoder (xDeepFMPro: a vocabulary-wide softmax head per sparse
+            # field over the positive rows, csrc/vocab_ce_x3.hip), at the mid vocabulary; `--workload criteo_pro` is the full line
+            pro = Run(preset_vocab("mid", cfg["n_sparse"]), cfg_=WORKLOADS["criteo_pro"])
+            pdt, _, _ = pro.timed(10, 3)
+            extras["sfg_pro_step"] = dict(value=round(B * 10 / pdt, 1), unit="examples/sec", ms_per_step=round(pdt / 10 * 1e3, 4),
+                                          model="xDeepFMPro, 26 heads of 1e5 x 64, positive rows only (about a quarter of the batch)",
+                                          parameters_M=round(sum(p.numel() for p in pro.model.parameters()) / 1e6, 1))
+            log("xDeepFMPro (mid vocabulary): %.3f ms/step" % (pdt / 10 * 1e3))
+            del pro
         lazy = Run(vocab, lazy_rows=True)
         ldt, _, _ = lazy.timed(args.steps, args.warmup)
         extras["lazy_adam_opt_in"] = dict(
@@ -482,6 +499,13 @@ def main():
                 roof = dict(kernel=name.replace("[bytes]", ""), bound="hbm", achieved=round(achieved, 1), peak=peak, unit="GB/s",
                             frac=round(achieved / peak, 4), traffic=None, launches=n, avg_ms=round(secs / n * 1e3, 4),
                             note="algorithmic bytes per launch (SURVEY.md 8d) / measured launch time")
+            elif name.startswith("vocab_ce"):
+                achieved, peak = work / secs / 1e12, CIN_MATH[1][1]
+                roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",
+                            frac=round(achieved / peak, 4), traffic=None, launches=n, avg_ms=round(secs / n * 1e3, 4),
+                            note="fp32-equivalent FLOPs of the reference's product (2 * positive rows * K * vocabulary rows of all "
+                                 "heads per launch; the backward kernels recompute the logits on top of their own product, which "
+                                 "is not counted); f16x3 on the matrix pipe, " + CIN_MATH[1][2])
             elif name.startswith("cin_attn_pool"):
                 achieved, peak = work / secs / 1e12, ATTN_PEAK_TFLOPS
                 roof = dict(kernel=name, bound="mfma", achieved=round(achieved, 2), peak=round(peak, 1), unit="TFLOP/s",

@@ -308,15 +308,19 @@ PRO_CASES = [
     ("pro_autodis",  [7, 5, 11, 3, 9, 4],  3,  4, (8, 6), (16, 8), (16, 8),    48, dict(sfg_positive_only=False, sfg_use_label_attention=False,
                                                                                        use_autodis=True, autodis_buckets=6, sfg_weight=0.3)),
     ("pro_nodense",  [13] * 22,            0,  8, (16, 8), (16,),  (12,),      32, dict()),
+    # heads of width 64 over vocabularies on both sides of the 256-row stages: the fused heads (csrc/vocab_ce_x3.hip) run
+    ("pro_heads64",  [300, 57, 1000, 33, 260, 5], 3, 4, (8, 6), (16, 8), (32, 64), 96, dict()),
 ]
 
 
-def gen_pro():
+def gen_pro(only_case=None):
     """deepctr/xdeepfm_pro: xDeepFMPro forward_with_sfg, every gradient of loss + reg + sfg_weight * sfg_loss, three Adam
     steps of the BaseModelSFG.fit loop body (basemodel_sfg.py:317-349), predict; sfg_dropout = 0 (the dropout masks of two
     generators cannot agree)."""
     from deepctr.xdeepfm_pro.xdeepfm_pro import xDeepFMPro
     for name, vocab, nd, D, cin, dnn, sfgh, B, kw in PRO_CASES:
+        if only_case and name != only_case:
+            continue
         sparse, dense, cols = _columns(vocab, nd, D)
         model = xDeepFMPro(cols, cols, dnn_hidden_units=dnn, cin_layer_size=cin, l2_reg_dnn=1e-5, device="cpu",
                            sfg_hidden_units=sfgh, sfg_dropout=0.0, **kw)
@@ -370,6 +374,8 @@ def gen_pro():
         for k, v in state3.items():
             arrays["s3:" + k] = v
         _save(name, **arrays)
+    if only_case:
+        return
     # History of BaseModelSFG.fit (basemodel_sfg.py:224-400): keys incl. sfg_loss
     vocab, nd, D = [9, 6, 12, 5], 2, 4
     sparse, dense, cols = _columns(vocab, nd, D)
@@ -406,7 +412,10 @@ def gen_metrics():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    only = sys.argv[1:]                  # e.g. `make_golden.py pro` regenerates one family
+    only = sys.argv[1:]                  # e.g. `make_golden.py pro` regenerates one family, `pro:pro_heads64` one case of it
+    for a in [a for a in only if a.startswith("pro:")]:
+        gen_pro(a.split(":", 1)[1])
+        only = [o for o in only if o != a] or ["-"]
     for fam, fn in (("cin", gen_cin), ("attn", gen_attn), ("models", gen_models), ("fit", gen_fit_history),
                     ("pro", gen_pro), ("metrics", gen_metrics)):
         if not only or fam in only:

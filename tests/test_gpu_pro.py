@@ -38,9 +38,11 @@ def test_pro_model_vs_reference_golden(name):
     """xDeepFMPro (deepctr/xdeepfm_pro/xdeepfm_pro.py:31-274): construction draws the reference's initial weights (same
     RNG order, same state_dict keys); forward_with_sfg -> y_pred, BCE, sfg loss; every gradient of
     BCE + L2 + sfg_weight * sfg_loss; three steps of the fit loop body (basemodel_sfg.py:317-349); predict."""
+    from xdfm_amd import ops
     dev = _dev()
     g = load_golden(name)
     model = _build(g, dev)
+    fused_before = ops.VocabHeadsCE.calls
     sd = model.state_dict()
     init = {k[5:]: g[k] for k in g if k.startswith("init:")}
     assert sorted(sd.keys()) == sorted(init.keys())
@@ -76,6 +78,9 @@ def test_pro_model_vs_reference_golden(name):
         np.testing.assert_allclose(v.cpu().numpy(), want, rtol=2e-3, atol=3e-6 + 2e-4 * float(np.abs(want).max()) * 1e-2, err_msg="after 3 steps " + k)
     pred = model.predict([X[:, i] for i in range(X.shape[1])], batch_size=B)
     np.testing.assert_allclose(pred, g["pred_after"], rtol=2e-4, atol=2e-6)
+    # heads of width 32 / 64 take the fused kernels (logits only in MFMA accumulators), the others the tiled path
+    fused = ops.VocabHeadsCE.calls - fused_before
+    assert fused == (4 if int(g["sfg_hidden"][-1]) in (32, 64) else 0), fused
 
 
 def test_pro_fit_history_vs_reference_golden():

@@ -19,7 +19,7 @@ tabs = [torch.randn(V, D, device=dev).requires_grad_(True) for _ in range(m)]
 lins = [torch.randn(V, 1, device=dev).requires_grad_(True) for _ in range(m)]
 w = torch.randn(nd, 1, device=dev).requires_grad_(True)
 plan = ops.EmbedPlan(list(range(m)), [V] * m, list(range(m, m + nd)), D)
-for B in (4096, 16384, 65536, 262144, 1048576):
+for B in [int(b) for b in os.environ.get("XDFM_GATHER_B", "4096,16384,65536,262144,1048576").split(",")]:
     X = torch.cat([torch.randint(0, V, (B, m), device=dev).float(), torch.rand(B, nd, device=dev)], 1)
     fwd_bytes = B * (4 * (m + nd) + m * (4 * D + 4) + 4 * m * D + 4 * (m * D + nd) + 4)
     bwd_bytes = B * (4 * (m + nd) + 2 * 4 * m * D + 4 + 4 * m * (D + 1))

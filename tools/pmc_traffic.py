@@ -2,12 +2,16 @@
 """Turn the two rocprofv3 --pmc passes of tools/pmc_cin.py (FETCH_SIZE, WRITE_SIZE) into a per-kernel, per-launch
 HBM-traffic table.  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B fabric requests as 64 B for
 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM section), so fetched bytes = 2 x FETCH_SIZE; WRITE_SIZE is exact.
-Usage: tools/pmc_traffic.py <fetch_dir> <write_dir> [out.json]"""
+Usage: tools/pmc_traffic.py <fetch_dir> <write_dir> [out.json|-] [grid]"""
 import collections
 import csv
 import glob
 import json
 import sys
+
+
+OWN = ("cin", "x3", "embed", "adam", "attn", "vx_", "head", "l2", "colsum", "vocab")      # this library's kernels
+BY_GRID = len(sys.argv) > 4 and sys.argv[4] == "grid"
 
 
 def load(d, counter):
@@ -17,8 +21,10 @@ def load(d, counter):
         if r["Counter_Name"] != counter:
             continue
         n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")
-        if "cin" not in n and "x3" not in n:
+        if n.startswith(("at::", "Cijk", "__amd", "rccl", "nccl")) or not any(k in n for k in OWN):
             continue
+        if BY_GRID:                              # the same kernel at several problem sizes (tools/gather_scale.py)
+            n += " grid=%s" % r.get("Grid_Size", "?")
         per[n].append((float(r["Counter_Value"]) * 1024.0, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3))
     return per
 
@@ -35,5 +41,5 @@ for k in sorted(F):
     fa, wa, ua = sum(f) / len(f), (sum(w) / len(w) if w else 0.0), sum(us) / len(us)
     out[k] = dict(launches=len(f), fetch_bytes=fa, write_bytes=wa, total_bytes=fa + wa, avg_us=ua)
     print("| %s | %d | %.1f | %.1f | %.1f | %.1f | %.0f |" % (k, len(f), fa / 1e6, wa / 1e6, (fa + wa) / 1e6, ua, (fa + wa) / ua / 1e3))
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[3] != "-":
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -882,9 +882,12 @@ class VocabHeadsCE(torch.autograd.Function):
     partials + merge in the forward; in the backward the hidden gradient (partial slabs summed in a fixed order) and
     the weight / bias gradients (every row written once, the target's -g included)."""
 
+    calls = 0                 # forward passes taken (tests assert that a golden reached this path)
+
     @staticmethod
     def forward(ctx, hidden, targets, *params):
         lib = _lib.load()
+        VocabHeadsCE.calls += 1
         F_ = len(params) // 2
         Ws, bs = params[:F_], params[F_:]
         R, K = hidden.shape
@@ -903,8 +906,10 @@ class VocabHeadsCE(torch.autograd.Function):
         lse2 = torch.zeros(F_, Rpad, dtype=torch.float32, device=dev)
         wmax = torch.empty(F_, dtype=torch.int32, device=dev)
         ws = torch.empty(plan[3], dtype=torch.float32, device=dev)
-        _lib.check(lib.xdfm_vocab_ce_fwd(_ptr(pack), _ptr(hidden), K, R, K, _ptr(fields), F_, _ptr(plan[1]), plan[2], _ptr(targets),
-                                         _ptr(ws), _ptr(ce), _ptr(lse2), _ptr(wmax), _stream()), "vocab_ce_fwd")
+        flops = 2.0 * R * K * sum(w.shape[0] for w in Ws)                  # of the reference's nn.Linear, all heads
+        _lib.check(_run("vocab_ce_fwd", flops, lambda: lib.xdfm_vocab_ce_fwd(
+            _ptr(pack), _ptr(hidden), K, R, K, _ptr(fields), F_, _ptr(plan[1]), plan[2], _ptr(targets), _ptr(ws), _ptr(ce), _ptr(lse2),
+            _ptr(wmax), _stream())), "vocab_ce_fwd")
         ctx.save_for_backward(hidden, targets, pack, lse2, wmax, *params)
         ctx.plan = plan
         return ce
@@ -922,6 +927,7 @@ class VocabHeadsCE(torch.autograd.Function):
         g = g.contiguous()
         Rpad = lib.xdfm_vocab_ce_rows_padded(R)
         gpack = torch.empty(F_ * (4 + Rpad), dtype=torch.float32, device=dev)
+        flops = 2.0 * R * K * sum(w.shape[0] for w in Ws)     # per product of the reference's backward (dH; dW), recompute not counted
         _lib.check(lib.xdfm_vocab_ce_pack_g(_ptr(g), F_, R, _ptr(gpack), _stream()), "vocab_ce_pack_g")
         dWs = [torch.empty_like(Ws[f]) if ctx.needs_input_grad[2 + f] else None for f in range(F_)]
         dbs = [torch.empty_like(bs[f]) if ctx.needs_input_grad[2 + F_ + f] else None for f in range(F_)]
@@ -930,11 +936,13 @@ class VocabHeadsCE(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dh = torch.empty_like(hidden)
             ws = torch.empty(plan[3], dtype=torch.float32, device=dev)
-            _lib.check(lib.xdfm_vocab_ce_bwd_h(_ptr(pack), R, K, _ptr(fields), F_, _ptr(plan[1]), plan[2], _ptr(targets), _ptr(g),
-                                               _ptr(gpack), _ptr(lse2), _ptr(wmax), _ptr(ws), _ptr(dh), K, _stream()), "vocab_ce_bwd_h")
+            _lib.check(_run("vocab_ce_bwd_h", flops, lambda: lib.xdfm_vocab_ce_bwd_h(
+                _ptr(pack), R, K, _ptr(fields), F_, _ptr(plan[1]), plan[2], _ptr(targets), _ptr(g), _ptr(gpack), _ptr(lse2), _ptr(wmax),
+                _ptr(ws), _ptr(dh), K, _stream())), "vocab_ce_bwd_h")
         if any(t is not None for t in dWs + dbs):
-            _lib.check(lib.xdfm_vocab_ce_bwd_w(_ptr(pack), R, K, _ptr(fields), F_, plan[4], _ptr(targets), _ptr(gpack), _ptr(lse2),
-                                               _ptr(wmax), _stream()), "vocab_ce_bwd_w")
+            _lib.check(_run("vocab_ce_bwd_w", flops, lambda: lib.xdfm_vocab_ce_bwd_w(
+                _ptr(pack), R, K, _ptr(fields), F_, plan[4], _ptr(targets), _ptr(gpack), _ptr(lse2), _ptr(wmax), _stream())),
+                "vocab_ce_bwd_w")
         return (dh, None, *dWs, *dbs)
 
 
