@@ -280,7 +280,7 @@ int xdfm_cin_level_bwd_w_prepared(const float* dOut, const float* xp, const floa
  * nh     number of heads (must divide D; pairs (D, nh) are compiled for D in {4,8,10,16,32}).
  * out    [B][D] pooled vector.  (CINAttention's output_proj D -> featuremap_num is a plain GEMM.)
  * tok_save, o_save [n_layers][B][S][D] (each layer's output tokens / attention output before W_o),
- * ml_save [n_layers][B][S][nh][2] (softmax max, 1/sum): written by fwd, read by bwd.
+ * ml_save [n_layers][B][S][nh][2] (base-2 log-sum-exp of the scaled scores, 1/sum): written by fwd, read by bwd.
  * bwd: dout [B][D]; dfm [S][B*D] is overwritten; dtheta (same layout as theta) is ACCUMULATED into with
  * fp32 atomics and must be zeroed by the caller.  S <= 1024.
  * p_drop, drop_seed: attention dropout (cin_attention.py:86, nn.Dropout on the softmax output, training mode

@@ -138,6 +138,25 @@ __device__ __forceinline__ float drop_keep(unsigned row_key, int t, unsigned thr
     return drop_mix(row_key + (unsigned)t * 0x9E3779B1U) >= thresh ? keep_scale : 0.f;
 }
 
+// The softmax runs in base 2 with the score scale folded into the query: q2 = q * (log2(e) / sqrt(head_dim)), so
+// exp(score - max) = exp2(q2 . k - max2) is one subtraction and one v_exp_f32 per (query, key, head) -- no scale multiply,
+// no log2(e) multiply.  Forward and backward use the same q2 and the same saved statistic lg = max2 + log2(sum), so the
+// backward's p = exp2(q2 . k - lg) is the forward's normalised probability without another multiply; the factors the
+// gradients owe (scale for dq, 1 / log2(e) for dk, which is accumulated against q2) are applied once per row at the end.
+#define ATTN_LOG2E 1.4426950408889634f
+#define ATTN_LN2 0.6931471805599453f
+__device__ __forceinline__ float attn_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+template <int D, int NH>
+__device__ __forceinline__ void head_dots(const float (&q)[D], const float (&k)[D], float (&sc)[NH]) {
+    constexpr int HD = D / NH;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < HD; ++e) a = fmaf(q[h * HD + e], k[h * HD + e], a);
+        sc[h] = a;
+    }
+}
 // ---------------------------------------------------------------------------------------------
 // scores of one query against key row t, all heads
 template <int D, int NH>
@@ -232,6 +251,9 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
     }
     float qi[D];
     head_interleave<D, NH>(q, qi);
+    const float c2 = scale * ATTN_LOG2E;
+#pragma unroll
+    for (int i = 0; i < D; ++i) qi[i] *= c2;            // q2: scores come out in base-2 units
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < NH; ++h) { mx[h] = -3.0e38f; ls[h] = 0.f; }
@@ -239,7 +261,7 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
     for (int t = 0; t < S; ++t) {                       // pass 1: row maxima (F.softmax subtracts them)
         float k[D], sc[NH];
         load_row<D>(Ks + t * D, k);
-        head_scores_il<D, NH>(qi, k, scale, sc);
+        head_dots_il<D, NH>(qi, k, sc);
 #pragma unroll
         for (int h = 0; h < NH; ++h) mx[h] = fmaxf(mx[h], sc[h]);
     }
@@ -251,10 +273,10 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
         float k[D], v[D], sc[NH];
         load_row<D>(Ks + t * D, k);
         load_row<D>(Vs + t * D, v);
-        head_scores_il<D, NH>(qi, k, scale, sc);
+        head_dots_il<D, NH>(qi, k, sc);
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const float p = __expf(sc[h] - mx[h]);
+            const float p = attn_exp2(sc[h] - mx[h]);
             ls[h] += p;                                  // the softmax normaliser is over ALL keys; the mask comes after
             const float pm = DROP ? p * drop_keep(rk[h], t, thresh, keep_scale) : p;
 #pragma unroll
@@ -334,7 +356,7 @@ __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
             store_row<D>(o_save + (((long)layer * B + b) * S + s) * D, on);
             float* ml = ml_save + ((((long)layer * B + b) * S + s) * NH) * 2;
 #pragma unroll
-            for (int h = 0; h < NH; ++h) { ml[2 * h] = mx[h]; ml[2 * h + 1] = 1.0f / ls[h]; }
+            for (int h = 0; h < NH; ++h) { ml[2 * h] = mx[h] + __builtin_amdgcn_logf(ls[h]); ml[2 * h + 1] = 1.0f / ls[h]; }   // lg (base 2), 1 / sum
         }
     }
 
@@ -578,14 +600,13 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             const float* og = o_save + ((long)layer * B + b) * S * D;
             const float* xrow = xg + (long)sl * xgp;
             const float* orow = og + (long)sl * D;
-            float mx[NH], il[NH];
+            float lg[NH];                                // base-2 log-sum-exp of the query's scores: p = exp2(q2 . k - lg)
             {
                 const float* ml = ml_save + ((((long)layer * B + b) * S + (live ? s : 0)) * NH) * 2;
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    const float t0 = ml[2 * h], t1 = ml[2 * h + 1];      // unconditional (clamped row), then masked
-                    mx[h] = live ? t0 : 0.f;
-                    il[h] = live ? t1 : 0.f;
+                    const float t0 = ml[2 * h];                          // unconditional (clamped row), then masked
+                    lg[h] = live ? t0 : 1.0e30f;                         // a dead thread's probabilities are 0
                 }
             }
             __syncthreads();
@@ -665,38 +686,41 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             unsigned rk[NH];
 #pragma unroll
             for (int h = 0; h < NH; ++h) rk[h] = DROP ? drop_row_key(*drop.seed, b, layer, n_layers, h, NH, s) : 0u;
-            float dq[D];
+            float dq[D], q2[D];
+            const float c2 = scale * ATTN_LOG2E;
 #pragma unroll
-            for (int d = 0; d < D; ++d) dq[d] = 0.f;
+            for (int d = 0; d < D; ++d) { dq[d] = 0.f; q2[d] = q[d] * c2; }
 #pragma unroll 2
             for (int t = 0; t < S; ++t) {
                 float k[D], v[D], sc[NH];
                 load_row<D>(Ks + t * D, k);
                 load_row<D>(Vs + t * D, v);
-                head_scores<D, NH>(q, k, scale, sc);
+                head_dots<D, NH>(q2, k, sc);
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    const float p = __expf(sc[h] - mx[h]) * il[h];
+                    const float p = attn_exp2(sc[h] - lg[h]);
                     float dp = 0.f;
 #pragma unroll
                     for (int e = 0; e < HD; ++e) dp = fmaf(dO[h * HD + e], v[h * HD + e], dp);
                     if (DROP) dp *= drop_keep(rk[h], t, drop.thresh, drop.keep_scale);
-                    const float ds = p * (dp - delta[h]) * scale;
+                    const float ds = p * (dp - delta[h]);               // * scale: once per row, below
 #pragma unroll
                     for (int e = 0; e < HD; ++e) dq[h * HD + e] = fmaf(ds, k[h * HD + e], dq[h * HD + e]);
                 }
             }
+#pragma unroll
+            for (int d = 0; d < D; ++d) dq[d] *= scale;
             __syncthreads();                             // all reads of K / V and of Ys / Zs are done
             // stage Q, dO and the row statistics for the key-side pass (over the K / V storage)
             float* Qs = Ks;
             float* dOs = Vs;
             if (live) {
-                store_row<D>(Qs + s * D, q);
+                store_row<D>(Qs + s * D, q2);
                 store_row<D>(dOs + s * D, dO);
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
-                    St[(s * NH + h) * 4] = mx[h];
-                    St[(s * NH + h) * 4 + 1] = il[h];
+                    St[(s * NH + h) * 4] = lg[h];
+                    St[(s * NH + h) * 4 + 1] = 0.f;
                     St[(s * NH + h) * 4 + 2] = delta[h];
                     St[(s * NH + h) * 4 + 3] = __uint_as_float(rk[h]);
                 }
@@ -715,17 +739,17 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                 float qs[D], dos[D], sc[NH];
                 load_row<D>(Qs + r * D, qs);
                 load_row<D>(dOs + r * D, dos);
-                head_scores<D, NH>(qs, kk, scale, sc);
+                head_dots<D, NH>(qs, kk, sc);                         // qs = the query's q2
 #pragma unroll
                 for (int h = 0; h < NH; ++h) {
                     const float4 stq = *reinterpret_cast<const float4*>(St + (r * NH + h) * 4);
-                    const float p = __expf(sc[h] - stq.x) * stq.y;
+                    const float p = attn_exp2(sc[h] - stq.x);
                     const float keep = DROP ? drop_keep(__float_as_uint(stq.w), s, drop.thresh, drop.keep_scale) : 1.f;
                     float dp = 0.f;
 #pragma unroll
                     for (int e = 0; e < HD; ++e) dp = fmaf(dos[h * HD + e], vv[h * HD + e], dp);
                     if (DROP) dp *= keep;
-                    const float ds = p * (dp - stq.z) * scale;
+                    const float ds = p * (dp - stq.z);                  // * scale * q = * q2 / log2(e): once per row, below
                     const float pv = DROP ? p * keep : p;
 #pragma unroll
                     for (int e = 0; e < HD; ++e) {
@@ -734,6 +758,8 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                     }
                 }
             }
+#pragma unroll
+            for (int d = 0; d < D; ++d) dk[d] *= ATTN_LN2;
             if (!live) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }

@@ -40,6 +40,12 @@ __device__ __forceinline__ float vx_wave_max(float v) {
 }
 __device__ __forceinline__ float vx_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// words[i * stride] = 0 (a kernel, not a memset node: captured graphs with memset nodes are not replayable on this stack)
+__global__ void vx_zero_words_kernel(unsigned* __restrict__ w, int n, int stride) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[(long)i * stride] = 0u;
+}
+
 // out[y] = max(out[y], bits(max |x[y * stride + i]|, i < n)) -- non-negative floats order like their bit patterns
 __global__ __launch_bounds__(256) void vx_absmax_kernel(const float* __restrict__ x, long n, long stride, unsigned* __restrict__ out, int out_stride) {
     const float* __restrict__ p = x + (long)blockIdx.y * stride;
@@ -477,18 +483,18 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
         float dbacc = 0.f;
 
         h8 stage[PER];
-        float stage_l = 0.f;
+        unsigned stage_l = 0u;                              // bits of lse2 / gs, or a target id
         auto fetch = [&](int t) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const int e = threadIdx.x + i * 64 * VX_WS_WAVES;
                 stage[i] = e < NHF ? Hf[(long)t * NHF + e] : HTf[(long)t * NHT + (e - NHF)];
             }
-            if (threadIdx.x < 64) stage_l = threadIdx.x < 32 ? lse2[32L * t + threadIdx.x] : gs[32L * t + threadIdx.x - 32];
+            if (threadIdx.x < 64) stage_l = __float_as_uint(threadIdx.x < 32 ? lse2[32L * t + threadIdx.x] : gs[32L * t + threadIdx.x - 32]);
             else if (threadIdx.x < 96) {
                 const long row = 32L * t + threadIdx.x - 64;
                 const long tv = row < R ? tgt[row] : -1;
-                stage_l = __int_as_float(row < R ? (int)(tv < 0 ? 0 : (tv >= V ? V - 1 : tv)) : -1);
+                stage_l = (unsigned)(row < R ? (int)(tv < 0 ? 0 : (tv >= V ? V - 1 : tv)) : -1);
             }
         };
         auto park = [&](int buf) {
@@ -497,9 +503,9 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
                 const int e = threadIdx.x + i * 64 * VX_WS_WAVES;
                 if (e < NHF) L[buf].hf[e] = stage[i]; else L[buf].htf[e - NHF] = stage[i];
             }
-            if (threadIdx.x < 32) L[buf].lse[threadIdx.x] = stage_l;
-            else if (threadIdx.x < 64) L[buf].gs[threadIdx.x - 32] = stage_l;
-            else if (threadIdx.x < 96) L[buf].tgt[threadIdx.x - 64] = __float_as_int(stage_l);
+            if (threadIdx.x < 32) L[buf].lse[threadIdx.x] = __uint_as_float(stage_l);
+            else if (threadIdx.x < 64) L[buf].gs[threadIdx.x - 32] = __uint_as_float(stage_l);
+            else if (threadIdx.x < 96) L[buf].tgt[threadIdx.x - 64] = (int)stage_l;
         };
         __syncthreads();                                   // the previous block's last tile is consumed
         fetch(0);
@@ -644,7 +650,7 @@ int xdfm_vocab_ce_pack_hidden(const float* H, long ldh, int R, int K, float* pac
     XDFM_REQUIRE(R > 0 && vx_k_ok(K) && ldh == K, "vocab_ce_pack_hidden: bad shape R=%d K=%d ld=%ld (rows must be contiguous)", R, K, ldh);
     hipStream_t st = (hipStream_t)stream;
     unsigned* hmax = reinterpret_cast<unsigned*>(pack) + 4;
-    if (hipMemsetAsync(hmax, 0, sizeof(unsigned), st) != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "vocab_ce_pack_hidden: memset");
+    hipLaunchKernelGGL(vx_zero_words_kernel, dim3(1), dim3(64), 0, st, hmax, 1, 1);
     const int tiles = ceil_div(R, 32);
     int gx = ceil_div((long)R * K, 256 * 8);
     gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
@@ -664,7 +670,7 @@ int xdfm_vocab_ce_fwd(const float* pack, const float* H, long ldh, int R, int K,
     hipStream_t st = (hipStream_t)stream;
     const long Rpad = vx_rows_padded(R);
     const int ntiles = ceil_div(R, 32);
-    if (hipMemsetAsync(wmax, 0, sizeof(unsigned) * F, st) != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "vocab_ce_fwd: memset");
+    hipLaunchKernelGGL(vx_zero_words_kernel, dim3(ceil_div(F, 64)), dim3(64), 0, st, wmax, F, 1);
     const h8* Hf = reinterpret_cast<const h8*>(pack + 16);
     const dim3 grid((unsigned)n_items, ceil_div(R, VX_RG)), block(64 * VX_WAVES);
     if (K == 64)
@@ -681,7 +687,7 @@ int xdfm_vocab_ce_pack_g(const float* g, int F, int R, float* gpack, void* strea
     XDFM_REQUIRE(g && gpack && R > 0 && F > 0, "vocab_ce_pack_g: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const long Rpad = vx_rows_padded(R);
-    if (hipMemsetAsync(gpack, 0, 4 * sizeof(float) * F, st) != hipSuccess) return xdfm_fail(XDFM_ERR_LAUNCH, "vocab_ce_pack_g: memset");
+    hipLaunchKernelGGL(vx_zero_words_kernel, dim3(ceil_div(F, 64)), dim3(64), 0, st, reinterpret_cast<unsigned*>(gpack) + 2, F, 4);
     int gx = ceil_div(R, 2048);
     gx = gx > 64 ? 64 : gx;
     hipLaunchKernelGGL(vx_absmax_kernel, dim3(gx, F), dim3(256), 0, st, g, (long)R, (long)R, reinterpret_cast<unsigned*>(gpack) + 2, 4);
