@@ -795,22 +795,37 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
     else { for (int i = threadIdx.x; i < asz; i += blockDim.x) atomicAdd(&dtheta[i], Acc[i]); }
 }
 
-// dtheta[i] = sum over the workgroups of part[g][i], in workgroup order: 8 loads in flight, one add chain
-__global__ __launch_bounds__(256) void attn_dtheta_finish_kernel(const float* __restrict__ part, int asz, int groups,
-                                                                 float* __restrict__ dtheta) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= asz) return;
+// dtheta[i] = sum over the workgroups of part[g][i] in a FIXED tree: 16 contiguous ranges of workgroups, each summed in
+// order by one thread (8 loads in flight), the 16 range sums added in range order -- the same bits on every run, and 16
+// times the parallelism of one chain per element (a single chain over 2048 partials took 99 us at config 3).
+#define ATTN_FIN_R 16
+__global__ __launch_bounds__(64 * ATTN_FIN_R) void attn_dtheta_finish_kernel(const float* __restrict__ part, int asz, int groups,
+                                                                             float* __restrict__ dtheta) {
+    __shared__ float red[ATTN_FIN_R][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + c;
+    const int per = (groups + ATTN_FIN_R - 1) / ATTN_FIN_R;
+    const int g0 = r * per, g1 = min(groups, g0 + per);
     float s = 0.f;
-    int g = 0;
-    for (; g + 8 <= groups; g += 8) {
-        float t[8];
+    if (i < asz) {
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {
+            float t[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) t[q] = part[(long)(g + q) * asz + i];
+            for (int q = 0; q < 8; ++q) t[q] = part[(long)(g + q) * asz + i];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s += t[q];
+            for (int q = 0; q < 8; ++q) s += t[q];
+        }
+        for (; g < g1; ++g) s += part[(long)g * asz + i];
     }
-    for (; g < groups; ++g) s += part[(long)g * asz + i];
-    dtheta[i] = s;
+    red[r][c] = s;
+    __syncthreads();
+    if (r == 0 && i < asz) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < ATTN_FIN_R; ++q) t += red[q][c];
+        dtheta[i] = t;
+    }
 }
 
 static inline int attn_bwd_groups(int B) { return B < 2048 ? B : 2048; }       // workgroups of the backward launch
@@ -834,7 +849,7 @@ static int launch_attn_bwd(const float* fm, int B, int S, int n_layers, int use_
 #undef XDFM_ATTN_BWD
     if (part) {
         const int asz = n_layers * (4 * D * D + (use_ln ? 2 * D : 0)) + D * D + 2 * D;
-        hipLaunchKernelGGL(attn_dtheta_finish_kernel, dim3(ceil_div(asz, 256)), dim3(256), 0, st, part, asz, grid, dtheta);
+        hipLaunchKernelGGL(attn_dtheta_finish_kernel, dim3(ceil_div(asz, 64)), dim3(64 * ATTN_FIN_R), 0, st, part, asz, grid, dtheta);
     }
     return xdfm_check_launch("cin_attn_pool_bwd");
 }

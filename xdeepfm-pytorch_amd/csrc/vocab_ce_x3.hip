@@ -271,33 +271,87 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
             }
         };
         if constexpr (MODE == 0) {
-            // software pipeline inside the wave: the MFMAs of block wb + 1 are issued before the exponentials of block wb
+            // A wave issues in order: behind a chain of dependent MFMAs its own VALU instructions wait, and the two waves
+            // of a SIMD run the same phase after every barrier.  So the log-sum-exp of block wb is dealt, by hand, between
+            // the MFMAs of block wb + 1: 12 slots of [one MFMA per tile, a slice of the epilogue], fenced so that hipcc
+            // keeps the order.  The operands of block wb + 2 and the bias of block wb + 1 are read from LDS into the
+            // registers the slots have just released.
             f32x16 acc[2][2];
-            auto lse_step = [&](int wb, const f32x16 (&a)[2]) {
-                const float cw = VX_LOG2E * invH * Linv[wb];
-                float b2[16];
-                bias_of(wb, b2);
+            h8 ah[KS], al[KS];
+            float b2[16], cw;
+            auto load_frag = [&](int wb, int s) {
+                ah[s] = La[((wb * KS + s) * 2 + 0) * 64 + lane];
+                al[s] = La[((wb * KS + s) * 2 + 1) * 64 + lane];
+            };
+            auto load_bias = [&](int wb) { bias_of(wb, b2); cw = VX_LOG2E * invH * Linv[wb]; };
+            auto mma = [&](f32x16 (&an)[2], int k) {              // slot k: term k % 3 of k-step k / 3, both tiles
+                const int ks = k / 3, term = k % 3;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float z[16], mx = VX_NEG;
+                for (int t = 0; t < 2; ++t)
+                    an[t] = term == 0 ? x3_mfma<3>(al[ks], bh[t][ks], an[t])
+                          : term == 1 ? x3_mfma<3>(ah[ks], bl[t][ks], an[t]) : x3_mfma<3>(ah[ks], bh[t][ks], an[t]);
+            };
+            float z[2][16], mx[2], mn[2], ex[2], sum[2];
+            auto slice = [&](const f32x16 (&ac)[2], int k) {      // slice k of the epilogue of the block in `ac`
+                if (k < 4) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { z[r] = fmaf(a[t][r], cw, b2[r]); mx = fmaxf(mx, z[r]); }
-                    const float mn = fmaxf(st_m[t], mx);
-                    float sum = 0.f;
+                    for (int t = 0; t < 2; ++t) {
+                        if (k == 0) mx[t] = VX_NEG;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sum += vx_exp2(z[r] - mn);
-                    st_s[t] = fmaf(st_s[t], vx_exp2(st_m[t] - mn), sum);
-                    st_m[t] = mn;
+                        for (int r = 4 * k; r < 4 * k + 4; ++r) { z[t][r] = fmaf(ac[t][r], cw, b2[r]); mx[t] = fmaxf(mx[t], z[t][r]); }
+                        if (k == 3) { mn[t] = fmaxf(st_m[t], mx[t]); ex[t] = vx_exp2(st_m[t] - mn[t]); sum[t] = 0.f; }
+                    }
+                } else {
+                    const int t = (k - 4) >> 2, r0 = 4 * ((k - 4) & 3);
+#pragma unroll
+                    for (int r = r0; r < r0 + 4; ++r) sum[t] += vx_exp2(z[t][r] - mn[t]);
+                    if (k == 11) {
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) { st_s[u] = fmaf(st_s[u], ex[u], sum[u]); st_m[u] = mn[u]; }
+                    }
                 }
             };
-            zmma(0, acc[0]);
-#pragma unroll 1
-            for (int wb = 0; wb < VX_WAVES; wb += 2) {
-                zmma(wb + 1, acc[1]);
-                lse_step(wb, acc[0]);
-                if (wb + 2 < VX_WAVES) zmma(wb + 2, acc[0]);
-                lse_step(wb + 1, acc[1]);
+            auto zero = [&](f32x16 (&a)[2]) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[t][r] = 0.f;
+            };
+            // block 0: nothing to run under its MFMAs
+#pragma unroll
+            for (int q = 0; q < KS; ++q) load_frag(0, q);
+            zero(acc[0]);
+#pragma unroll
+            for (int k = 0; k < 3 * KS; ++k) {
+                mma(acc[0], k);
+                if (k % 3 == 2) load_frag(1, k / 3);
             }
+            load_bias(0);
+            __builtin_amdgcn_sched_barrier(0);
+            auto step = [&](f32x16 (&ac)[2], f32x16 (&an)[2], int wb) {      // MFMAs of block wb + 1 over the epilogue of block wb
+                const int nn = wb + 2 < VX_WAVES ? wb + 2 : VX_WAVES - 1;    // operands to fetch next (clamped: the last fetch is idle)
+                zero(an);
+#pragma unroll
+                for (int k = 0; k < 3 * KS; ++k) {
+                    mma(an, k);
+                    if (k < 12) slice(ac, k);
+                    if (k % 3 == 2) load_frag(nn, k / 3);
+                    if (k == 3) load_bias(wb + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (3 * KS < 12) {
+#pragma unroll
+                    for (int k = 3 * KS; k < 12; ++k) slice(ac, k);
+                }
+            };
+#pragma unroll 1
+            for (int wb = 0; wb < VX_WAVES - 2; wb += 2) {
+                step(acc[0], acc[1], wb);
+                step(acc[1], acc[0], wb + 1);
+            }
+            step(acc[0], acc[1], VX_WAVES - 2);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) slice(acc[1], k);        // the stage's last block: its bias was fetched in the step above
         } else {
 #pragma unroll 1
             for (int wb = 0; wb < VX_WAVES; ++wb) {
