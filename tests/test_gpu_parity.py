@@ -294,7 +294,8 @@ def test_cin_bf16_mfma_path_vs_fp32_oracle(B, m, D, ls, act):
         _lib.set_option("cin_math", old)
 
 
-def test_model_in_bf16_cin_arithmetic_tracks_the_fp32_modes():
+@pytest.mark.parametrize("B", [512, 4096])          # 4096 = BASELINE config 5's per-GPU batch
+def test_model_in_bf16_cin_arithmetic_tracks_the_fp32_modes(B):
     """Whole model, config-5 shape (22 sparse fields, D = 32, cin (512,256,256,128)), 6 Adam steps in cin_math 2 and in
     cin_math 1 from the same initial weights on the same batches: losses within 2e-3 relative, predictions within 5e-3
     absolute, logloss / AUC of the final predictions within 2e-3 -- the bf16 tolerance of SURVEY 8(d)."""
@@ -303,7 +304,7 @@ def test_model_in_bf16_cin_arithmetic_tracks_the_fp32_modes():
     from oracle import xdeepfm_oracle as orc
     from xdfm_amd import _lib, metrics as M
     dev = _dev()
-    vocab, D, B = [500] * 22, 32, 512
+    vocab, D = [500] * 22, 32
     cols = [SparseFeat("C%d" % (i + 1), v, D) for i, v in enumerate(vocab)]
     old = _lib.get_option("cin_math")
 
