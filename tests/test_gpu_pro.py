@@ -140,9 +140,13 @@ def test_vocab_softmax_ce_tiles_vs_materialised_logits(rows, K, V, tile_bytes):
         np.testing.assert_allclose(got.cpu().numpy(), w, rtol=2e-4, atol=2e-5 * float(np.abs(w).max()), err_msg=name)
 
 
-@pytest.mark.parametrize("rows,K,vocabs", [(300, 64, (50000, 77, 1000)), (17, 32, (1000, 33)), (1, 64, (5,)),
-                                           (1100, 64, (70001, 256)), (513, 32, (4097,))])
-def test_vocab_heads_ce_fused_vs_materialised_logits(rows, K, vocabs):
+@pytest.mark.parametrize("rows,K,vocabs,hs,ws_", [(300, 64, (50000, 77, 1000), 1.0, 0.3), (17, 32, (1000, 33), 1.0, 0.3),
+                                                  (1, 64, (5,), 1.0, 0.3), (1100, 64, (70001, 256), 1.0, 0.3),
+                                                  (513, 32, (4097,), 1.0, 0.3),
+                                                  (4096, 64, (3000, 129), 1.0, 0.3),          # eight row groups (no positive-only filter)
+                                                  (200, 64, (5000,), 1.0e3, 3.0e-4),          # operand ranges far from 1: the power-of-two scales
+                                                  (200, 64, (5000,), 1.0, 1.5)])              # logits of +-40: the log-sum-exp's range
+def test_vocab_heads_ce_fused_vs_materialised_logits(rows, K, vocabs, hs, ws_):
     """ops.VocabHeadsCE (csrc/vocab_ce_x3.hip): the heads of all sparse fields over the same hidden rows with the logits
     only in MFMA accumulators (sfg_decoder.py:146-149 + :277-283) -- losses and all gradients against the materialised
     computation in float64; ragged row counts (tiles of 32, row groups of 512), vocabularies that are no multiple of the
@@ -152,11 +156,13 @@ def test_vocab_heads_ce_fused_vs_materialised_logits(rows, K, vocabs):
     dev = _dev()
     assert ops.vocab_heads_ce_supported(K) and not ops.vocab_heads_ce_supported(48)
     g = torch.Generator().manual_seed(rows + sum(vocabs))
-    h = torch.randn(rows, K, generator=g).to(dev).requires_grad_(True)
-    Ws = [(torch.randn(V, K, generator=g) * 0.3).to(dev).requires_grad_(True) for V in vocabs]
+    h = (torch.randn(rows, K, generator=g) * hs).to(dev).requires_grad_(True)
+    Ws = [(torch.randn(V, K, generator=g) * ws_).to(dev).requires_grad_(True) for V in vocabs]
     bs = [(torch.randn(V, generator=g) * 0.3).to(dev).requires_grad_(True) for V in vocabs]
     tgt = torch.stack([torch.randint(0, V, (rows,), generator=g) for V in vocabs]).to(dev)
-    gout = (torch.rand(len(vocabs), rows, generator=g) * 1e-3).to(dev)
+    gout = (torch.rand(len(vocabs), rows, generator=g) - 0.3) * 1e-3         # both signs
+    gout[:, ::7] = 0.0                                                        # and exact zeros (rows the loss masks)
+    gout = gout.to(dev)
     ce = ops.vocab_heads_ce(h, tgt, Ws, bs)
     (ce * gout).sum().backward()
     h64 = h.detach().double().requires_grad_(True)

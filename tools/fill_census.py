@@ -12,10 +12,10 @@ from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
 import bench  # noqa: E402
 
-workload = sys.argv[1] if len(sys.argv) > 1 else "criteo_c2"
+workload = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in bench.WORKLOADS else "criteo_c2"
 cfg = bench.WORKLOADS[workload]
 dev = torch.device("cuda:0")
-vocab = [100000] * cfg["n_sparse"]
+vocab = bench.preset_vocab("criteo-card", cfg["n_sparse"]) if "card" in sys.argv else [100000] * cfg["n_sparse"]
 os.environ["XDFM_HIP_GRAPH"] = "0"
 model = bench.build_model(cfg, vocab, dev)
 model.train()
