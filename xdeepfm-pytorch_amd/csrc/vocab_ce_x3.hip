@@ -157,7 +157,7 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
     int tile[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        tile[t] = blockIdx.y * (2 * VX_WAVES) + 2 * w + t;
+        tile[t] = blockIdx.y * (2 * VX_WAVES) + w + VX_WAVES * t;      // a group's first 8 tiles: one per wave
         const int ti = tile[t] < ntiles ? tile[t] : 0;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -166,6 +166,9 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
             if (tile[t] >= ntiles) { bh[t][s] = (h8)(_Float16)0; bl[t][s] = (h8)(_Float16)0; }
         }
     }
+    // a row group with at most 8 tiles (the tail of R just above a multiple of 512, or a small batch) has no second tile in
+    // any wave: its stages run the one-tile instance of the consume loop (workgroup-uniform)
+    const bool two = ntiles - (int)blockIdx.y * (2 * VX_WAVES) > VX_WAVES;
     float st_m[2] = {VX_NEG, VX_NEG}, st_s[2] = {0.f, 0.f};        // MODE 0: running base-2 maximum and sum per lane
     float r_lse[2] = {0.f, 0.f}, r_gs[2] = {0.f, 0.f};             // MODE 1: the lane's example
     f32x16 dacc[2][KT];
@@ -243,7 +246,8 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
         publish(sb);
         __syncthreads();
         if (sb + 1 < sb1) load_w(sb + 1);               // in flight while this stage is consumed
-        auto zmma = [&](int wb, f32x16 (&acc)[2]) {            // z^T of the stage's block wb against both tiles
+        auto zmma = [&](auto ntc, int wb, f32x16 (&acc)[2]) {  // z^T of the stage's block wb against the wave's NT tiles
+            constexpr int NT = decltype(ntc)::value;
             h8 ah[KS], al[KS];
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
@@ -251,13 +255,13 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
                 al[s] = La[((wb * KS + s) * 2 + 1) * 64 + lane];
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
+                for (int t = 0; t < NT; ++t) {
                     acc[t] = x3_mfma<3>(al[s], bh[t][s], acc[t]);
                     acc[t] = x3_mfma<3>(ah[s], bl[t][s], acc[t]);
                     acc[t] = x3_mfma<3>(ah[s], bh[t][s], acc[t]);
@@ -276,6 +280,8 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
             // the MFMAs of block wb + 1: 12 slots of [one MFMA per tile, a slice of the epilogue], fenced so that hipcc
             // keeps the order.  The operands of block wb + 2 and the bias of block wb + 1 are read from LDS into the
             // registers the slots have just released.
+            auto consume = [&](auto ntc) {
+            constexpr int NT = decltype(ntc)::value;
             f32x16 acc[2][2];
             h8 ah[KS], al[KS];
             float b2[16], cw;
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
             auto mma = [&](f32x16 (&an)[2], int k) {              // slot k: term k % 3 of k-step k / 3, both tiles
                 const int ks = k / 3, term = k % 3;
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < NT; ++t)
                     an[t] = term == 0 ? x3_mfma<3>(al[ks], bh[t][ks], an[t])
                           : term == 1 ? x3_mfma<3>(ah[ks], bl[t][ks], an[t]) : x3_mfma<3>(ah[ks], bh[t][ks], an[t]);
             };
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
             auto slice = [&](const f32x16 (&ac)[2], int k) {      // slice k of the epilogue of the block in `ac`
                 if (k < 4) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < NT; ++t) {
                         if (k == 0) mx[t] = VX_NEG;
 #pragma unroll
                         for (int r = 4 * k; r < 4 * k + 4; ++r) { z[t][r] = fmaf(ac[t][r], cw, b2[r]); mx[t] = fmaxf(mx[t], z[t][r]); }
@@ -303,17 +309,19 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
                     }
                 } else {
                     const int t = (k - 4) >> 2, r0 = 4 * ((k - 4) & 3);
+                    if (t < NT) {
 #pragma unroll
-                    for (int r = r0; r < r0 + 4; ++r) sum[t] += vx_exp2(z[t][r] - mn[t]);
+                        for (int r = r0; r < r0 + 4; ++r) sum[t] += vx_exp2(z[t][r] - mn[t]);
+                    }
                     if (k == 11) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) { st_s[u] = fmaf(st_s[u], ex[u], sum[u]); st_m[u] = mn[u]; }
+                        for (int u = 0; u < NT; ++u) { st_s[u] = fmaf(st_s[u], ex[u], sum[u]); st_m[u] = mn[u]; }
                     }
                 }
             };
             auto zero = [&](f32x16 (&a)[2]) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) a[t][r] = 0.f;
             };
@@ -352,17 +360,21 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
             step(acc[0], acc[1], VX_WAVES - 2);
 #pragma unroll
             for (int k = 0; k < 12; ++k) slice(acc[1], k);        // the stage's last block: its bias was fetched in the step above
+            };
+            if (two) consume(std::integral_constant<int, 2>{}); else consume(std::integral_constant<int, 1>{});
         } else {
+            auto consume = [&](auto ntc) {
+            constexpr int NT = decltype(ntc)::value;
 #pragma unroll 1
             for (int wb = 0; wb < VX_WAVES; ++wb) {
                 const float cw = VX_LOG2E * invH * Linv[wb];
                 float b2[16];
                 bias_of(wb, b2);
                 f32x16 acc[2];
-                zmma(wb, acc);
+                zmma(ntc, wb, acc);
                 h8 ph[2][2], pl[2][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int sp = 0; sp < 2; ++sp)
 #pragma unroll
@@ -381,13 +393,15 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
                         const h8* f = reinterpret_cast<const h8*>(Lwt) + (((wb * KT + kt) * 2 + sp) * 2) * 64 + lane;
                         const h8 wh = f[0], wl = f[64];
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
+                        for (int t = 0; t < NT; ++t) {
                             dacc[t][kt] = x3_mfma<3>(wl, ph[t][sp], dacc[t][kt]);
                             dacc[t][kt] = x3_mfma<3>(wh, pl[t][sp], dacc[t][kt]);
                             dacc[t][kt] = x3_mfma<3>(wh, ph[t][sp], dacc[t][kt]);
                         }
                     }
             }
+            };
+            if (two) consume(std::integral_constant<int, 2>{}); else consume(std::integral_constant<int, 1>{});
         }
         __syncthreads();
     }
