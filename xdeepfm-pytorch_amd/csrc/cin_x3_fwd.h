@@ -46,13 +46,7 @@ __device__ __forceinline__ void x3_split2(float z0, float z1, h2& hi, h2& lo) {
 // lo = rne16(a*b - hi) with the exact product inside one v_fma_mix_f32 per element (its third operand is the
 // fp16 half, read in place) -- 5 VALU instructions per pair.
 __device__ __forceinline__ void x3_split_prod2(float a0, float b0, float a1, float b1, h2& hi, h2& lo) {
-#ifdef X3_SCALAR_MUL
-    f2 z;                                                // two v_mul_f32: packed fp32 math beside MFMAs costs more than it saves
-    asm("v_mul_f32 %0, %1, %2" : "=v"(z.x) : "v"(a0), "v"(b0));
-    asm("v_mul_f32 %0, %1, %2" : "=v"(z.y) : "v"(a1), "v"(b1));
-#else
-    const f2 z = (f2){a0, a1} * (f2){b0, b1};
-#endif
+    const f2 z = (f2){a0, a1} * (f2){b0, b1};        // (two v_mul_f32 instead of the packed multiply: measured, no difference)
     hi = __builtin_convertvector(z, h2);
     const unsigned hbits = __builtin_bit_cast(unsigned, hi);
     float r0, r1;
