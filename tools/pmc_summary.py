@@ -13,7 +13,7 @@ for r in csv.DictReader(open(cc)):
     n = r["Kernel_Name"]
     if flt not in n:
         continue
-    key = n.split("(")[0][-44:]
+    key = n[:44] if n.startswith("_Z") else n.split("(")[0][-44:]      # mangled names (templates): the head tells the instance
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
     agg[key]["_dur_ns"].append(kt.get(r["Dispatch_Id"], 0.0))
 for k, v in agg.items():
