@@ -39,6 +39,18 @@ __device__ __forceinline__ float vx_wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float vx_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// hi / lo fp16 halves of two fp32 values with the residual z - hi formed by one v_fma_mix_f32 per element (the fp16 half is
+// read in place): 4 vector instructions per pair instead of 6 -- the vector issue port is what bounds these kernels
+__device__ __forceinline__ void vx_split2(float z0, float z1, h2& hi, h2& lo) {
+    const f2 z = {z0, z1};
+    hi = __builtin_convertvector(z, h2);
+    const unsigned hb = __builtin_bit_cast(unsigned, hi);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(z0), "v"(hb));
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(z1), "v"(hb));
+    const f2 r = {r0, r1};
+    lo = __builtin_convertvector(r, h2);
+}
 
 // words[i * stride] = 0 (a kernel, not a memset node: captured graphs with memset nodes are not replayable on this stack)
 __global__ void vx_zero_words_kernel(unsigned* __restrict__ w, int n, int stride) {
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
         publish(sb);
         __syncthreads();
         if (sb + 1 < sb1) load_w(sb + 1);               // in flight while this stage is consumed
-        auto zmma = [&](auto ntc, int wb, f32x16 (&acc)[2]) {  // z^T of the stage's block wb against the wave's NT tiles
+        auto zmma = [&](auto ntc, int wb, f32x16 (&acc)[2], const float (&c0)[2]) {  // c0 + z^T of block wb against the wave's NT tiles
             constexpr int NT = decltype(ntc)::value;
             h8 ah[KS], al[KS];
 #pragma unroll
@@ -257,7 +269,7 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[t][r] = c0[t];
 #pragma unroll
             for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -365,13 +377,15 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
         } else {
             auto consume = [&](auto ntc) {
             constexpr int NT = decltype(ntc)::value;
+            const float icw = sWg / (VX_LOG2E * invH);           // 1 / cw (one scale for the whole head in this mode)
+            const float c0[2] = {-r_lse[0] * icw, -r_lse[1] * icw};
 #pragma unroll 1
             for (int wb = 0; wb < VX_WAVES; ++wb) {
                 const float cw = VX_LOG2E * invH * Linv[wb];
                 float b2[16];
                 bias_of(wb, b2);
                 f32x16 acc[2];
-                zmma(ntc, wb, acc);
+                zmma(ntc, wb, acc, c0);                 // accumulators start at -lse / cw: cw * acc + bias is logit - lse (base 2)
                 h8 ph[2][2], pl[2][2];
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -380,10 +394,10 @@ __global__ __launch_bounds__(64 * VX_WAVES) void vx_hs_kernel(
 #pragma unroll
                         for (int e = 0; e < 8; e += 2) {
                             const int r = 8 * sp + e;
-                            const float p0 = vx_exp2(fmaf(acc[t][r], cw, b2[r]) - r_lse[t]) * r_gs[t];
-                            const float p1 = vx_exp2(fmaf(acc[t][r + 1], cw, b2[r + 1]) - r_lse[t]) * r_gs[t];
+                            const float p0 = vx_exp2(fmaf(acc[t][r], cw, b2[r])) * r_gs[t];
+                            const float p1 = vx_exp2(fmaf(acc[t][r + 1], cw, b2[r + 1])) * r_gs[t];
                             h2 a, b;
-                            x3_split2(p0, p1, a, b);
+                            vx_split2(p0, p1, a, b);
                             ph[t][sp][e] = a.x; ph[t][sp][e + 1] = a.y; pl[t][sp][e] = b.x; pl[t][sp][e + 1] = b.y;
                         }
 #pragma unroll
@@ -486,31 +500,40 @@ __global__ __launch_bounds__(256) void vx_dh_merge_kernel(const float* __restric
     *reinterpret_cast<float4*>(dh + (long)r * lddh + k) = tot;
 }
 
-#define VX_WS_WAVES 4
+#define VX_WS_WAVES 8
+#define VX_WS_TP 2                       // row tiles per ring slot: one barrier and one fetch / park round per slot
 template <int KT>
-struct VxTileLds {                       // one row tile as the weights-stationary kernel consumes it
+struct VxSlotLds {                       // VX_WS_TP row tiles as the weights-stationary kernel consumes them
     static constexpr int KS = 2 * KT;
-    h8 hf[KS * 2 * 64];
-    h8 htf[KT * 2 * 2 * 64];
-    float lse[32], gs[32];
-    int tgt[32];
+    h8 hf[VX_WS_TP][KS * 2 * 64];
+    h8 htf[VX_WS_TP][KT * 2 * 2 * 64];
+    float lse[VX_WS_TP][32], gs[VX_WS_TP][32];
+    int tgt[VX_WS_TP][32];
 };
 
+// Measured with parts of the kernel switched off (tools/vocab_ce_dbg.py): its phases ADD -- MFMAs 1.0 ms, exponentials and
+// splits 0.7, tile ring and barriers 0.75, the rest 0.6 of 2.95 -- two waves per SIMD hide nothing of each other.  Hence 8
+// waves share one ring whose slots hold two tiles: half the barriers, fetches and LDS writes per tile.
 template <int KT>
-__global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
+__global__ __launch_bounds__(64 * VX_WS_WAVES, 1) void vx_ws_kernel(
     const h8* __restrict__ Hf, const h8* __restrict__ HTf, const float* __restrict__ hscale, int ntiles,
     const VxField* __restrict__ fields, int F, int nblk_all, const unsigned* __restrict__ wmax_all, const float* __restrict__ lse2_all,
-    const float* __restrict__ gpack, const long* __restrict__ tgt_all, int R, long Rpad) {
+    const float* __restrict__ gpack, const long* __restrict__ tgt_all, int R, long Rpad, int dbg) {
+    // dbg (option "dbg", bits 20..23; timing experiments, results become wrong): 1 = no exponentials / target test / split,
+    // 2 = no dW MFMAs, 4 = no z MFMAs, 8 = no tile ring traffic and no barriers
     constexpr int KS = 2 * KT, K = 32 * KT;
-    constexpr int NHF = KS * 2 * 64, NHT = KT * 2 * 2 * 64;            // h8 per tile
-    __shared__ VxTileLds<KT> L[3];                 // ring: the tile in work, the next one (its z is already being formed), the one arriving
+    constexpr int NHF = KS * 2 * 64, NHT = KT * 2 * 2 * 64, NTL = NHF + NHT;      // h8 per tile
+    constexpr int NTH = 64 * VX_WS_WAVES;
+    constexpr int PER = VX_WS_TP * NTL / NTH;                                     // h8 per thread and slot
+    static_assert(VX_WS_TP * NTL % NTH == 0 && NTL % NTH == 0 || NTL == NTH * PER / VX_WS_TP, "slot split");
+    extern __shared__ __attribute__((aligned(16))) char ws_smem[];
+    VxSlotLds<KT>* const L = reinterpret_cast<VxSlotLds<KT>*>(ws_smem);            // ring of 3 slots
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
-    constexpr int PER = (NHF + NHT) / (64 * VX_WS_WAVES);              // h8 per thread and tile (KT = 2: 4)
-    static_assert((NHF + NHT) % (64 * VX_WS_WAVES) == 0 && NHF % (64 * VX_WS_WAVES) == 0, "tile split");
+    const int nslots = (ntiles + VX_WS_TP - 1) / VX_WS_TP;
 
     for (int gb = blockIdx.x; gb < nblk_all; gb += gridDim.x) {
         int f = 0;
-        while (f + 1 < F && fields[f + 1].blk0 <= gb) ++f;              // the field this 128-row block belongs to
+        while (f + 1 < F && fields[f + 1].blk0 <= gb) ++f;              // the field this block of 256 vocabulary rows belongs to
         const VxField fd = fields[f];
         const float* __restrict__ W = fd.W;
         const float* __restrict__ bias = fd.bias;
@@ -522,6 +545,7 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
         const long* __restrict__ tgt = tgt_all + (long)f * R;
         const float sW = x3_pow2_scale(__uint_as_float(wmax_all[f]), 12);
         const float cw = VX_LOG2E * hscale[1] / sW;
+        const float icw = -1.f / cw;                           // the tiles' lse values are parked as -lse / cw: z starts there
         const float inv_b = gpack[4 * f + 1], inv_w = inv_b * hscale[1];
         const long v = (long)blk * (32 * VX_WS_WAVES) + 32 * w + c;
         const bool live = v < V;
@@ -551,16 +575,20 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
         float dbacc = 0.f;
 
         h8 stage[PER];
-        unsigned stage_l = 0u;                              // bits of lse2 / gs, or a target id
-        auto fetch = [&](int t) {
-#pragma unroll
+        unsigned stage_l = 0u;                              // bits of -lse2 / cw or gs, or a target id
+        auto fetch = [&](int sl) {                          // slot sl = tiles VX_WS_TP * sl ..; a tile past the last one repeats it with
+#pragma unroll                                              // zero gradients (gs is zero beyond R, the targets are -1)
             for (int i = 0; i < PER; ++i) {
-                const int e = threadIdx.x + i * 64 * VX_WS_WAVES;
-                stage[i] = e < NHF ? Hf[(long)t * NHF + e] : HTf[(long)t * NHT + (e - NHF)];
+                const int e = threadIdx.x + i * NTH;
+                const int u = e / NTL, r = e - u * NTL;
+                const int t = min(VX_WS_TP * sl + u, ntiles - 1);
+                stage[i] = r < NHF ? Hf[(long)t * NHF + r] : HTf[(long)t * NHT + (r - NHF)];
             }
-            if (threadIdx.x < 64) stage_l = __float_as_uint(threadIdx.x < 32 ? lse2[32L * t + threadIdx.x] : gs[32L * t + threadIdx.x - 32]);
-            else if (threadIdx.x < 96) {
-                const long row = 32L * t + threadIdx.x - 64;
+            const int q = threadIdx.x >> 6, i = threadIdx.x & 63;          // q: 0 lse, 1 gs, 2 targets; i: row within the slot
+            const long row = 32L * VX_WS_TP * sl + i;
+            if (q == 0) stage_l = __float_as_uint(lse2[row] * icw);
+            else if (q == 1) stage_l = __float_as_uint(gs[row]);
+            else if (q == 2) {
                 const long tv = row < R ? tgt[row] : -1;
                 stage_l = (unsigned)(row < R ? (int)(tv < 0 ? 0 : (tv >= V ? V - 1 : tv)) : -1);
             }
@@ -568,75 +596,88 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 2) void vx_ws_kernel(
         auto park = [&](int buf) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
-                const int e = threadIdx.x + i * 64 * VX_WS_WAVES;
-                if (e < NHF) L[buf].hf[e] = stage[i]; else L[buf].htf[e - NHF] = stage[i];
+                const int e = threadIdx.x + i * NTH;
+                const int u = e / NTL, r = e - u * NTL;
+                if (r < NHF) L[buf].hf[u][r] = stage[i]; else L[buf].htf[u][r - NHF] = stage[i];
             }
-            if (threadIdx.x < 32) L[buf].lse[threadIdx.x] = __uint_as_float(stage_l);
-            else if (threadIdx.x < 64) L[buf].gs[threadIdx.x - 32] = __uint_as_float(stage_l);
-            else if (threadIdx.x < 96) L[buf].tgt[threadIdx.x - 64] = (int)stage_l;
+            const int q = threadIdx.x >> 6, i = threadIdx.x & 63;
+            if (q == 0) L[buf].lse[i >> 5][i & 31] = __uint_as_float(stage_l);
+            else if (q == 1) L[buf].gs[i >> 5][i & 31] = __uint_as_float(stage_l);
+            else if (q == 2) L[buf].tgt[i >> 5][i & 31] = (int)stage_l;
         };
-        __syncthreads();                                   // the previous block's last tile is consumed
+        __syncthreads();                                   // the previous block's last slot is consumed
         fetch(0);
         park(0);
-        if (ntiles > 1) { fetch(1); park(1); }
+        if (nslots > 1) { fetch(1); park(1); }
         __syncthreads();
-        auto zmma = [&](int buf, f32x16& z) {
+        auto zmma = [&](int buf, int u, f32x16& z) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            for (int q = 0; q < 4; ++q) {                       // accumulators start at -lse[row] / cw
+                const float4 lq = *reinterpret_cast<const float4*>(L[buf].lse[u] + 8 * q + 4 * hh);
+                z[4 * q] = lq.x; z[4 * q + 1] = lq.y; z[4 * q + 2] = lq.z; z[4 * q + 3] = lq.w;
+            }
+            if (dbg & 4) return;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const h8 ah = L[buf].hf[(s * 2 + 0) * 64 + lane], al = L[buf].hf[(s * 2 + 1) * 64 + lane];
+                const h8 ah = L[buf].hf[u][(s * 2 + 0) * 64 + lane], al = L[buf].hf[u][(s * 2 + 1) * 64 + lane];
                 z = x3_mfma<3>(al, bh[s], z);
                 z = x3_mfma<3>(ah, bl[s], z);
                 z = x3_mfma<3>(ah, bh[s], z);
             }
         };
-        // one tile: the next tile's z MFMAs are issued first, so that they run under this tile's exponentials
-        auto tile_step = [&](int t, int buf, f32x16& z, f32x16& zn) {
-            const int bufn = buf == 2 ? 0 : buf + 1, bufa = bufn == 2 ? 0 : bufn + 1;
-            if (t + 2 < ntiles) fetch(t + 2);
-            if (t + 1 < ntiles) zmma(bufn, zn);
+        // one tile: P = g (softmax - onehot(target)) from its z (formed while the previous tile was here), then dW^T += H^T P
+        auto pstep = [&](int buf, int u, const f32x16& z) {
             h8 ph[2], pl[2];
+            if (dbg & 1) {
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { ph[sp][e] = (_Float16)z[8 * sp + e]; pl[sp][e] = (_Float16)0; }
+            } else
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 lq = *reinterpret_cast<const float4*>(L[buf].lse + 8 * q + 4 * hh);
-                const float4 gq = *reinterpret_cast<const float4*>(L[buf].gs + 8 * q + 4 * hh);
-                const int4 tq = *reinterpret_cast<const int4*>(L[buf].tgt + 8 * q + 4 * hh);
-                // g * (softmax - onehot(target)): the row's own target entry, so dW / db are complete when they are stored
-                const float p0 = (vx_exp2(fmaf(z[4 * q], cw, b2) - lq.x) - (tq.x == vi ? 1.f : 0.f)) * gq.x;
-                const float p1 = (vx_exp2(fmaf(z[4 * q + 1], cw, b2) - lq.y) - (tq.y == vi ? 1.f : 0.f)) * gq.y;
-                const float p2 = (vx_exp2(fmaf(z[4 * q + 2], cw, b2) - lq.z) - (tq.z == vi ? 1.f : 0.f)) * gq.z;
-                const float p3 = (vx_exp2(fmaf(z[4 * q + 3], cw, b2) - lq.w) - (tq.w == vi ? 1.f : 0.f)) * gq.w;
+                const float4 gq = *reinterpret_cast<const float4*>(L[buf].gs[u] + 8 * q + 4 * hh);
+                const int4 tq = *reinterpret_cast<const int4*>(L[buf].tgt[u] + 8 * q + 4 * hh);
+                // the row's own target entry is subtracted here, so dW / db are complete when they are stored
+                const float p0 = (vx_exp2(fmaf(z[4 * q], cw, b2)) - (tq.x == vi ? 1.f : 0.f)) * gq.x;
+                const float p1 = (vx_exp2(fmaf(z[4 * q + 1], cw, b2)) - (tq.y == vi ? 1.f : 0.f)) * gq.y;
+                const float p2 = (vx_exp2(fmaf(z[4 * q + 2], cw, b2)) - (tq.z == vi ? 1.f : 0.f)) * gq.z;
+                const float p3 = (vx_exp2(fmaf(z[4 * q + 3], cw, b2)) - (tq.w == vi ? 1.f : 0.f)) * gq.w;
                 dbacc += (p0 + p1) + (p2 + p3);
                 h2 a, b;
                 const int sp = q >> 1, e = 4 * (q & 1);
-                x3_split2(p0, p1, a, b);
+                vx_split2(p0, p1, a, b);
                 ph[sp][e] = a.x; ph[sp][e + 1] = a.y; pl[sp][e] = b.x; pl[sp][e + 1] = b.y;
-                x3_split2(p2, p3, a, b);
+                vx_split2(p2, p3, a, b);
                 ph[sp][e + 2] = a.x; ph[sp][e + 3] = a.y; pl[sp][e + 2] = b.x; pl[sp][e + 3] = b.y;
             }
+            if (!(dbg & 2)) {
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+                for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const h8 th = L[buf].htf[((kt * 2 + sp) * 2 + 0) * 64 + lane], tl = L[buf].htf[((kt * 2 + sp) * 2 + 1) * 64 + lane];
-                    acc[kt] = x3_mfma<3>(tl, ph[sp], acc[kt]);
-                    acc[kt] = x3_mfma<3>(th, pl[sp], acc[kt]);
-                    acc[kt] = x3_mfma<3>(th, ph[sp], acc[kt]);
-                }
-            if (t + 2 < ntiles) park(bufa);                // the slot of tile t - 1: every wave left it at the last barrier
-            __syncthreads();
+                    for (int sp = 0; sp < 2; ++sp) {
+                        const h8 th = L[buf].htf[u][((kt * 2 + sp) * 2 + 0) * 64 + lane], tl = L[buf].htf[u][((kt * 2 + sp) * 2 + 1) * 64 + lane];
+                        acc[kt] = x3_mfma<3>(tl, ph[sp], acc[kt]);
+                        acc[kt] = x3_mfma<3>(th, pl[sp], acc[kt]);
+                        acc[kt] = x3_mfma<3>(th, ph[sp], acc[kt]);
+                    }
+            } else { acc[0][0] += (float)ph[0][0] + (float)ph[1][3] + (float)pl[0][1] + (float)pl[1][5]; }
         };
         f32x16 za, zb;
-        zmma(0, za);
+        zmma(0, 0, za);
         int buf = 0;
-        for (int t = 0; t < ntiles; t += 2) {
-            tile_step(t, buf, za, zb);
-            buf = buf == 2 ? 0 : buf + 1;
-            if (t + 1 < ntiles) {
-                tile_step(t + 1, buf, zb, za);
-                buf = buf == 2 ? 0 : buf + 1;
+        for (int sl = 0; sl < nslots; ++sl) {
+            const int bufn = buf == 2 ? 0 : buf + 1, bufa = bufn == 2 ? 0 : bufn + 1;
+            if (sl + 2 < nslots && !(dbg & 8)) fetch(sl + 2);
+            zmma(buf, 1, zb);                                  // the next tile's z MFMAs are issued before this tile's exponentials
+            pstep(buf, 0, za);
+            if (sl + 1 < nslots) zmma(bufn, 0, za);
+            pstep(buf, 1, zb);
+            if (!(dbg & 8)) {
+                if (sl + 2 < nslots) park(bufa);               // the slot of two rounds ago: every wave left it at the last barrier
+                __syncthreads();
             }
+            buf = bufn;
         }
         const float dbo = dbacc + __shfl_xor(dbacc, 32);
         if (live) {
@@ -793,13 +834,14 @@ int xdfm_vocab_ce_bwd_w(const float* pack, int R, int K, const xdfm_vce_field* f
     const long Rpad = vx_rows_padded(R);
     const h8* Hf = reinterpret_cast<const h8*>(pack + 16);
     const h8* HTf = Hf + (long)tiles * (K / 16) * 2 * 64;
-    const int grid = n_blk < 4096 ? n_blk : 4096;
+    const int grid = n_blk < 1024 ? n_blk : 1024;              // one workgroup of 8 waves per CU at a time (100 KB of LDS)
+    const int dbg = (xdfm_opt(OPT_DBG) >> 20) & 15;
     if (K == 64)
-        hipLaunchKernelGGL((vx_ws_kernel<2>), dim3(grid), dim3(64 * VX_WS_WAVES), 0, st, Hf, HTf, pack, tiles, fields, F, n_blk, wmax, lse2,
-                           gpack, targets, R, Rpad);
+        hipLaunchKernelGGL((vx_ws_kernel<2>), dim3(grid), dim3(64 * VX_WS_WAVES), 3 * sizeof(VxSlotLds<2>), st, Hf, HTf, pack, tiles, fields, F,
+                           n_blk, wmax, lse2, gpack, targets, R, Rpad, dbg);
     else
-        hipLaunchKernelGGL((vx_ws_kernel<1>), dim3(grid), dim3(64 * VX_WS_WAVES), 0, st, Hf, HTf, pack, tiles, fields, F, n_blk, wmax, lse2,
-                           gpack, targets, R, Rpad);
+        hipLaunchKernelGGL((vx_ws_kernel<1>), dim3(grid), dim3(64 * VX_WS_WAVES), 3 * sizeof(VxSlotLds<1>), st, Hf, HTf, pack, tiles, fields, F,
+                           n_blk, wmax, lse2, gpack, targets, R, Rpad, dbg);
     return xdfm_check_launch("vocab_ce_bwd_w");
 }
 
