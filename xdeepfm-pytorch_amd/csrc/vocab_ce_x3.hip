@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * VX_WS_WAVES, 1) void vx_ws_kernel(
     constexpr int NHF = KS * 2 * 64, NHT = KT * 2 * 2 * 64, NTL = NHF + NHT;      // h8 per tile
     constexpr int NTH = 64 * VX_WS_WAVES;
     constexpr int PER = VX_WS_TP * NTL / NTH;                                     // h8 per thread and slot
-    static_assert(VX_WS_TP * NTL % NTH == 0 && NTL % NTH == 0 || NTL == NTH * PER / VX_WS_TP, "slot split");
+    static_assert(VX_WS_TP * NTL == NTH * PER && NTL % 64 == 0, "a slot is dealt evenly to the threads");
     extern __shared__ __attribute__((aligned(16))) char ws_smem[];
     VxSlotLds<KT>* const L = reinterpret_cast<VxSlotLds<KT>*>(ws_smem);            // ring of 3 slots
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = lane & 31, hh = lane >> 5;
