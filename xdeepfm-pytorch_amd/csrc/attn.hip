@@ -617,6 +617,16 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             matvec_acc<D>(WT, xrow, q);
             matvec_acc<D>(WT + D * D, xrow, kk);
             matvec_acc<D>(WT + 2 * D * D, xrow, vv);
+            // NH even: every per-head quantity of the two passes below is kept head-interleaved (element e of head h at
+            // e*NH + h, as the forward's K rows), so that one v_pk_fma_f32 serves two heads: K / V rows in LDS, q2, dO, and the
+            // accumulators dq, dk, dv (de-interleaved once at the end)
+            constexpr bool IL = (NH % 2 == 0);
+            if (IL) { float t[D]; head_interleave<D, NH>(kk, t);
+#pragma unroll
+                for (int d = 0; d < D; ++d) kk[d] = t[d];
+                head_interleave<D, NH>(vv, t);
+#pragma unroll
+                for (int d = 0; d < D; ++d) vv[d] = t[d]; }
             if (live) {
                 store_row<D>(Ks + s * D, kk);
                 store_row<D>(Vs + s * D, vv);
@@ -690,6 +700,49 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             const float c2 = scale * ATTN_LOG2E;
 #pragma unroll
             for (int d = 0; d < D; ++d) { dq[d] = 0.f; q2[d] = q[d] * c2; }
+            if constexpr (IL) {
+                float q2i[D], dOi[D];
+                head_interleave<D, NH>(q2, q2i);
+                head_interleave<D, NH>(dO, dOi);
+                attn_f2 dqi[D / 2], lg2[NH / 2], dl2[NH / 2];
+#pragma unroll
+                for (int i = 0; i < D / 2; ++i) dqi[i] = (attn_f2){0.f, 0.f};
+#pragma unroll
+                for (int hp = 0; hp < NH / 2; ++hp) { lg2[hp] = (attn_f2){lg[2 * hp], lg[2 * hp + 1]}; dl2[hp] = (attn_f2){delta[2 * hp], delta[2 * hp + 1]}; }
+#pragma unroll 2
+                for (int t = 0; t < S; ++t) {
+                    float k[D], v[D];
+                    load_row<D>(Ks + t * D, k);
+                    load_row<D>(Vs + t * D, v);
+#pragma unroll
+                    for (int hp = 0; hp < NH / 2; ++hp) {
+                        attn_f2 sc = {0.f, 0.f}, dp = {0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < HD; ++e) {
+                            const attn_f2 kp = {k[e * NH + 2 * hp], k[e * NH + 2 * hp + 1]};
+                            const attn_f2 vp = {v[e * NH + 2 * hp], v[e * NH + 2 * hp + 1]};
+                            sc = __builtin_elementwise_fma((attn_f2){q2i[e * NH + 2 * hp], q2i[e * NH + 2 * hp + 1]}, kp, sc);
+                            dp = __builtin_elementwise_fma((attn_f2){dOi[e * NH + 2 * hp], dOi[e * NH + 2 * hp + 1]}, vp, dp);
+                        }
+                        sc -= lg2[hp];
+                        const attn_f2 pr = {attn_exp2(sc.x), attn_exp2(sc.y)};
+                        if (DROP) dp *= (attn_f2){drop_keep(rk[2 * hp], t, drop.thresh, drop.keep_scale),
+                                                  drop_keep(rk[2 * hp + 1], t, drop.thresh, drop.keep_scale)};
+                        const attn_f2 ds = pr * (dp - dl2[hp]);           // * scale: once per row, below
+#pragma unroll
+                        for (int e = 0; e < HD; ++e)
+                            dqi[(e * NH + 2 * hp) / 2] = __builtin_elementwise_fma(ds, (attn_f2){k[e * NH + 2 * hp], k[e * NH + 2 * hp + 1]},
+                                                                                   dqi[(e * NH + 2 * hp) / 2]);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) {
+                        const int i = e * NH + h;
+                        dq[h * HD + e] = (i & 1) ? dqi[i / 2].y : dqi[i / 2].x;
+                    }
+            } else {
 #pragma unroll 2
             for (int t = 0; t < S; ++t) {
                 float k[D], v[D], sc[NH];
@@ -708,6 +761,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                     for (int e = 0; e < HD; ++e) dq[h * HD + e] = fmaf(ds, k[h * HD + e], dq[h * HD + e]);
                 }
             }
+            }
 #pragma unroll
             for (int d = 0; d < D; ++d) dq[d] *= scale;
             __syncthreads();                             // all reads of K / V and of Ys / Zs are done
@@ -715,6 +769,20 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             float* Qs = Ks;
             float* dOs = Vs;
             if (live) {
+                if constexpr (IL) {
+                    float t1[D];
+                    head_interleave<D, NH>(q2, t1);
+                    store_row<D>(Qs + s * D, t1);
+                    head_interleave<D, NH>(dO, t1);
+                    store_row<D>(dOs + s * D, t1);
+                    // statistics by kind: [lg of the NH heads | delta | dropout row key | -]: a head pair is 8 adjacent bytes
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        St[s * 4 * NH + h] = lg[h];
+                        St[s * 4 * NH + NH + h] = delta[h];
+                        St[s * 4 * NH + 2 * NH + h] = __uint_as_float(rk[h]);
+                    }
+                } else {
                 store_row<D>(Qs + s * D, q2);
                 store_row<D>(dOs + s * D, dO);
 #pragma unroll
@@ -723,6 +791,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                     St[(s * NH + h) * 4 + 1] = 0.f;
                     St[(s * NH + h) * 4 + 2] = delta[h];
                     St[(s * NH + h) * 4 + 3] = __uint_as_float(rk[h]);
+                }
                 }
             }
 #pragma unroll
@@ -734,6 +803,54 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
             float dk[D], dv[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+            if constexpr (IL) {
+                attn_f2 dki[D / 2], dvi[D / 2];
+#pragma unroll
+                for (int i = 0; i < D / 2; ++i) { dki[i] = (attn_f2){0.f, 0.f}; dvi[i] = (attn_f2){0.f, 0.f}; }
+#pragma unroll 2
+                for (int r = 0; r < S; ++r) {
+                    float qs[D], dos[D], stl[NH], std_[NH], strk[NH];
+                    load_row<D>(Qs + r * D, qs);
+                    load_row<D>(dOs + r * D, dos);
+                    load_row<NH>(St + r * 4 * NH, stl);
+                    load_row<NH>(St + r * 4 * NH + NH, std_);
+                    if (DROP) load_row<NH>(St + r * 4 * NH + 2 * NH, strk);
+#pragma unroll
+                    for (int hp = 0; hp < NH / 2; ++hp) {
+                        attn_f2 sc = {0.f, 0.f}, dp = {0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < HD; ++e) {
+                            const int i = e * NH + 2 * hp;
+                            sc = __builtin_elementwise_fma((attn_f2){qs[i], qs[i + 1]}, (attn_f2){kk[i], kk[i + 1]}, sc);
+                            dp = __builtin_elementwise_fma((attn_f2){dos[i], dos[i + 1]}, (attn_f2){vv[i], vv[i + 1]}, dp);
+                        }
+                        sc -= (attn_f2){stl[2 * hp], stl[2 * hp + 1]};
+                        const attn_f2 pr = {attn_exp2(sc.x), attn_exp2(sc.y)};
+                        attn_f2 pv = pr;
+                        if (DROP) {
+                            const attn_f2 keep = {drop_keep(__float_as_uint(strk[2 * hp]), s, drop.thresh, drop.keep_scale),
+                                                  drop_keep(__float_as_uint(strk[2 * hp + 1]), s, drop.thresh, drop.keep_scale)};
+                            dp *= keep;
+                            pv = pr * keep;
+                        }
+                        const attn_f2 ds = pr * (dp - (attn_f2){std_[2 * hp], std_[2 * hp + 1]});    // * q2 / log2(e): below
+#pragma unroll
+                        for (int e = 0; e < HD; ++e) {
+                            const int i = e * NH + 2 * hp;
+                            dvi[i / 2] = __builtin_elementwise_fma(pv, (attn_f2){dos[i], dos[i + 1]}, dvi[i / 2]);
+                            dki[i / 2] = __builtin_elementwise_fma(ds, (attn_f2){qs[i], qs[i + 1]}, dki[i / 2]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+#pragma unroll
+                    for (int e = 0; e < HD; ++e) {
+                        const int i = e * NH + h;
+                        dk[h * HD + e] = (i & 1) ? dki[i / 2].y : dki[i / 2].x;
+                        dv[h * HD + e] = (i & 1) ? dvi[i / 2].y : dvi[i / 2].x;
+                    }
+            } else {
 #pragma unroll 2
             for (int r = 0; r < S; ++r) {
                 float qs[D], dos[D], sc[NH];
@@ -757,6 +874,7 @@ __global__ __launch_bounds__(TB) void attn_pool_bwd_kernel(
                         dk[h * HD + e] = fmaf(ds, qs[h * HD + e], dk[h * HD + e]);
                     }
                 }
+            }
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) dk[d] *= ATTN_LN2;
