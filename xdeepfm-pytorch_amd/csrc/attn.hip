@@ -257,31 +257,52 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < NH; ++h) { mx[h] = -3.0e38f; ls[h] = 0.f; }
-#pragma unroll 2
-    for (int t = 0; t < S; ++t) {                       // pass 1: row maxima (F.softmax subtracts them)
-        float k[D], sc[NH];
-        load_row<D>(Ks + t * D, k);
-        head_dots_il<D, NH>(qi, k, sc);
-#pragma unroll
-        for (int h = 0; h < NH; ++h) mx[h] = fmaxf(mx[h], sc[h]);
-    }
+    // One pass over the keys, in blocks of KB: scores of the block, the running maximum moves to the block's maximum (the
+    // sums so far are rescaled by exp2(old - new): nothing after the first blocks, where the maximum settles), then the
+    // block's exponentials and P.V.  The separate maximum pass this replaces computed every score twice.
     float o[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) o[d] = 0.f;
-#pragma unroll 2
-    for (int t = 0; t < S; ++t) {                       // pass 2: exp, row sums, P.V
-        float k[D], v[D], sc[NH];
-        load_row<D>(Ks + t * D, k);
-        load_row<D>(Vs + t * D, v);
-        head_dots_il<D, NH>(qi, k, sc);
+    auto block = [&](auto kbc, int t0) {
+        constexpr int KB = decltype(kbc)::value;
+        float sc[KB][NH], bm[NH];
+#pragma unroll
+        for (int h = 0; h < NH; ++h) bm[h] = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            float k[D];
+            load_row<D>(Ks + (t0 + j) * D, k);
+            head_dots_il<D, NH>(qi, k, sc[j]);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) bm[h] = fmaxf(bm[h], sc[j][h]);
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            const float p = attn_exp2(sc[h] - mx[h]);
-            ls[h] += p;                                  // the softmax normaliser is over ALL keys; the mask comes after
-            const float pm = DROP ? p * drop_keep(rk[h], t, thresh, keep_scale) : p;
+            const float mn = fmaxf(mx[h], bm[h]);
+            const float corr = attn_exp2(mx[h] - mn);    // 0 for the first block (mx = -3e38), 1 once the maximum has settled
+            ls[h] *= corr;
 #pragma unroll
-            for (int e = 0; e < HD; ++e) o[h * HD + e] = fmaf(pm, v[h * HD + e], o[h * HD + e]);
+            for (int e = 0; e < HD; ++e) o[h * HD + e] *= corr;
+            mx[h] = mn;
         }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            float v[D];
+            load_row<D>(Vs + (t0 + j) * D, v);
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const float p = attn_exp2(sc[j][h] - mx[h]);
+                ls[h] += p;                              // the softmax normaliser is over ALL keys; the mask comes after
+                const float pm = DROP ? p * drop_keep(rk[h], t0 + j, thresh, keep_scale) : p;
+#pragma unroll
+                for (int e = 0; e < HD; ++e) o[h * HD + e] = fmaf(pm, v[h * HD + e], o[h * HD + e]);
+            }
+        }
+    };
+    {
+        int t0 = 0;
+        for (; t0 + 8 <= S; t0 += 8) block(std::integral_constant<int, 8>{}, t0);
+        for (; t0 < S; ++t0) block(std::integral_constant<int, 1>{}, t0);
     }
     // a = (residual x) + W_o (o / l)
 #pragma unroll
