@@ -61,6 +61,19 @@ __device__ __forceinline__ void store_row(float* __restrict__ p, const float (&r
 // y[i] += sum_d MT[d][i] * xrow[d]   (MT = transposed weight in LDS, xrow = this thread's row in LDS).
 // The loop over d stays rolled: x is indexed dynamically (from LDS), y statically (registers), and
 // only one weight row is live at a time -- a fully unrolled D x D matvec spills.
+// the same with the vector's elements `xs` floats apart (the forward keeps its tokens element-major in LDS: [D][threads],
+// conflict-free without a padding column -- the 1 KB that padding cost was what kept a third workgroup off the CU)
+template <int D>
+__device__ __forceinline__ void matvec_acc_s(const float* __restrict__ MT, const float* __restrict__ x, int xs, float (&y)[D]) {
+#pragma unroll 2
+    for (int d = 0; d < D; ++d) {
+        const float xd = x[d * xs];
+        float w[D];
+        load_row<D>(MT + d * D, w);
+#pragma unroll
+        for (int i = 0; i < D; ++i) y[i] = fmaf(w[i], xd, y[i]);
+    }
+}
 template <int D>
 __device__ __forceinline__ void matvec_acc(const float* __restrict__ MT, const float* __restrict__ xrow, float (&y)[D]) {
 #pragma unroll 2
@@ -220,8 +233,8 @@ __device__ __forceinline__ void head_scores_il(const float (&q)[D], const float 
     for (int h = 0; h < NH; ++h) sc[h] *= scale;
 }
 
-// One MHSA layer for the token of this thread.  The token lives in the thread's row of Xs ([S][D+1],
-// padded pitch: every thread reads its own row) and is replaced there by the layer's output
+// One MHSA layer for the token of this thread.  The token lives in the thread's column of Xs ([D][threads],
+// element-major: conflict-free without padding) and is replaced there by the layer's output
 // (post residual / LayerNorm), which is also returned in a.  Ks/Vs: [S][D] LDS; WT: this layer's
 // weights in LDS, matrices transposed.  mx / ls: softmax statistics of the thread's query row.
 template <int D, int NH, bool DROP>
@@ -230,18 +243,18 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
                                                int use_ln, int use_res, const unsigned (&rk)[NH], unsigned thresh,
                                                float keep_scale) {
     constexpr int HD = D / NH;
-    constexpr int XP = D + 1;
+    const int XS = blockDim.x;                           // Xs is element-major: element d of this thread's token at Xs[d * XS + s]
     const int s = threadIdx.x;
-    float* xrow = Xs + s * XP;
+    float* xrow = Xs + s;
     const float scale = 1.0f / sqrtf((float)HD);
     float q[D];
     {
         float kk[D], vv[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) { q[i] = 0.f; kk[i] = 0.f; vv[i] = 0.f; }
-        matvec_acc<D>(WT, xrow, q);
-        matvec_acc<D>(WT + D * D, xrow, kk);
-        matvec_acc<D>(WT + 2 * D * D, xrow, vv);
+        matvec_acc_s<D>(WT, xrow, XS, q);
+        matvec_acc_s<D>(WT + D * D, xrow, XS, kk);
+        matvec_acc_s<D>(WT + 2 * D * D, xrow, XS, vv);
         float ki[D];
         head_interleave<D, NH>(kk, ki);
         if (live) {
@@ -306,17 +319,17 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
     }
     // a = (residual x) + W_o (o / l)
 #pragma unroll
-    for (int d = 0; d < D; ++d) a[d] = use_res ? xrow[d] : 0.f;
+    for (int d = 0; d < D; ++d) a[d] = use_res ? xrow[d * XS] : 0.f;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
         const float inv = 1.0f / ls[h];
 #pragma unroll
         for (int e = 0; e < HD; ++e) {
             on[h * HD + e] = o[h * HD + e] * inv;
-            xrow[h * HD + e] = on[h * HD + e];                              // own row: no barrier needed
+            xrow[(h * HD + e) * XS] = on[h * HD + e];                       // own column: no barrier needed
         }
     }
-    matvec_acc<D>(WT + 3 * D * D, xrow, a);
+    matvec_acc_s<D>(WT + 3 * D * D, xrow, XS, a);
     if (use_ln) {
         const float* g = WT + 4 * D * D;
         float mean = 0.f;
@@ -331,7 +344,7 @@ __device__ __forceinline__ void mhsa_layer_fwd(float (&a)[D], float (&on)[D], fl
         for (int d = 0; d < D; ++d) a[d] = (a[d] - mean) * rstd * g[d] + g[D + d];
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d) xrow[d] = a[d];
+    for (int d = 0; d < D; ++d) xrow[d * XS] = a[d];
 }
 
 // TB = compile-time bound of the block size (round_up(S, 64) threads): 512 leaves 256 VGPRs per lane
@@ -342,22 +355,22 @@ __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
     const float* __restrict__ theta, float* __restrict__ out, float* __restrict__ tok_save,
     float* __restrict__ o_save, float* __restrict__ ml_save, AttnDrop drop) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int XP = D + 1;
+    const int XS = blockDim.x;
     float* Ks = smem;                                    // [S][D]
     float* Vs = Ks + S * D;                              // [S][D]
     float* Ws = Vs + S * D;                              // 4*D*D + 2*D floats (weights of the current stage)
-    float* red = Ws + 4 * D * D + 2 * D;                 // 16 + 16*D floats
-    float* Xs = red + 16 + 16 * D;                       // [blockDim][D+1] tokens, one row per thread
+    float* red = Ws + 4 * D * D + 2 * D;                 // 16 + (waves of the block) * D floats
+    float* Xs = red + 16 + (XS >> 6) * D;                // [D][blockDim] tokens, element-major: one column per thread
     const int b = blockIdx.x;
     const int s = threadIdx.x;
     const bool live = s < S;
     const int lsz = 4 * D * D + (use_ln ? 2 * D : 0);
 
-    float* xrow = Xs + s * XP;
+    float* xrow = Xs + s;
 #pragma unroll
     for (int d = 0; d < D; ++d) {                        // unconditional load from a clamped row, masked afterwards:
         const float t = fm[(long)(live ? s : 0) * N + (long)b * D + d];   // behind `live ? load : 0` hipcc issues the loads one by one
-        xrow[d] = live ? t : 0.f;
+        xrow[d * XS] = live ? t : 0.f;
     }
 
     for (int layer = 0; layer < n_layers; ++layer) {
@@ -388,13 +401,13 @@ __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
     __syncthreads();
     float x[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) x[d] = xrow[d];
+    for (int d = 0; d < D; ++d) x[d] = xrow[d * XS];
     float e = 0.f;
     {
         float u[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) u[i] = Ws[D * D + i];
-        matvec_acc<D>(Ws, xrow, u);
+        matvec_acc_s<D>(Ws, xrow, XS, u);
 #pragma unroll
         for (int i = 0; i < D; ++i) e = fmaf(Ws[D * D + D + i], tanhf(u[i]), e);
     }
@@ -424,7 +437,8 @@ __global__ __launch_bounds__(TB) void attn_pool_fwd_kernel(
 
 // ---------------------------------------------------------------------------------------------
 static size_t attn_fwd_lds(int S, int D) {
-    return (size_t)(2 * S * D + 4 * D * D + 2 * D + 16 + 16 * D + round_up(S, 64) * (D + 1)) * sizeof(float);
+    const long threads = round_up(S, 64);
+    return (size_t)(2 * S * D + 4 * D * D + 2 * D + 16 + (threads / 64) * D + threads * D) * sizeof(float);
 }
 
 template <int D, int NH>
